@@ -1,0 +1,85 @@
+"""Seeded inputs + the golden case table shared by tests/golden/make_golden.py (which drives
+the REFERENCE's train()/validate()) and the tests (which drive the oracle and the HIP engine).
+
+Inputs follow the reference's batch contract: uint8 NCHW in [0,255], no
+normalisation; labeled batches ``[b,3,3,H,W]`` + ``[b,3]`` (dataset.py:487-536), unlabeled
+``([mu*b,3,H,W],[mu*b,3,H,W])`` (dataset.py:624-677), RSP ``3x[B,3,H,W] + [B,1]``
+(dataset.py:166-213).  numpy's legacy RandomState is bit-stable across versions.
+"""
+import numpy as np
+import torch
+
+
+def u8(seed, shape):
+    return torch.from_numpy(np.random.RandomState(seed).randint(0, 256, size=shape, dtype=np.uint8))
+
+
+def f32(seed, shape):
+    return torch.from_numpy(np.random.RandomState(seed).uniform(0.0, 1.0, size=shape).astype(np.float32))
+
+
+def ints(seed, shape, hi):
+    return torch.from_numpy(np.random.RandomState(seed).randint(0, hi, size=shape).astype(np.int64))
+
+
+# name -> config.  hw = image side; b = --batch_size; mu = --mu; nb = batches per epoch
+CASES = {
+    # eval_BreastPathQ_SSL_CR.train: MSE/MSE, Adam lr 1e-4 wd 1e-4 (:268-272,481); 256 is hard-coded (:74)
+    "bpq_cr_f60": dict(script="bpq_cr", hw=256, b=1, mu=2, nb=2, modules=60, classes=1, lr=1e-4, wd=1e-4,
+                       lambda_u=1.0, opt="adam"),
+    "bpq_cr_f0": dict(script="bpq_cr", hw=256, b=1, mu=2, nb=2, modules=0, classes=1, lr=1e-4, wd=1e-4,
+                      lambda_u=1.0, opt="adam"),
+    # eval_Camelyon_SSL_CR.train: CE + hard pseudo-label CE, SGD-Nesterov lr 5e-4 (:251-256,514)
+    "cam_cr_f60": dict(script="cam_cr", hw=64, b=2, mu=2, nb=2, modules=60, classes=2, lr=5e-4, wd=1e-4,
+                       lambda_u=1.0, opt="sgd"),
+    "cam_cr_f0": dict(script="cam_cr", hw=64, b=2, mu=2, nb=2, modules=0, classes=2, lr=5e-4, wd=1e-4,
+                      lambda_u=0.5, opt="sgd"),
+    # pretrain_BreastPathQ.train/validate: RSP 6-way CE, SGD-Nesterov lr .01 + Lookahead(5,.5) (:245-247)
+    "rsp": dict(script="rsp", hw=64, b=4, nb=2, classes=6, lr=0.01, wd=1e-4, opt="sgd"),
+    # eval_Camelyon_SSL.train: supervised CE (student only), SGD-Nesterov (:371)
+    "cam_sup": dict(script="cam_sup", hw=64, b=2, nb=2, modules=0, classes=2, lr=1e-3, wd=1e-4, opt="sgd"),
+    # eval_BreastPathQ_SSL.train: supervised MSE, Adam (:396); image side is args.image_size (:58)
+    "bpq_sup": dict(script="bpq_sup", hw=64, b=2, nb=2, modules=0, classes=1, lr=1e-3, wd=1e-4, opt="adam"),
+}
+
+PARAM_SEED = 42        # the reference's default --seed (eval_BreastPathQ_SSL_CR.py:253)
+
+
+def labeled_batches(case, seed0=1000):
+    """BreastPathQ-style labeled loader: [(x u8 [b,3,3,H,W], y f32 [b,3])] * nb."""
+    c = CASES[case]
+    return [(u8(seed0 + i, (c["b"], 3, 3, c["hw"], c["hw"])), f32(seed0 + 50 + i, (c["b"], 3)))
+            for i in range(c["nb"])]
+
+
+def labeled_batches_cls(case, seed0, label):
+    """Camelyon-style class loader: x u8 [b,3,3,H,W], y int64 [b,3] all == label."""
+    c = CASES[case]
+    return [(u8(seed0 + i, (c["b"], 3, 3, c["hw"], c["hw"])),
+             torch.full((c["b"], 3), label, dtype=torch.int64)) for i in range(c["nb"])]
+
+
+def unlabeled_batches(case, seed0=2000):
+    c = CASES[case]
+    n = c["b"] * c["mu"]
+    return [(u8(seed0 + i, (n, 3, c["hw"], c["hw"])), u8(seed0 + 50 + i, (n, 3, c["hw"], c["hw"])))
+            for i in range(c["nb"])]
+
+
+def rsp_batches(case, seed0=3000):
+    c = CASES[case]
+    return [(u8(seed0 + i, (c["b"], 3, c["hw"], c["hw"])), u8(seed0 + 20 + i, (c["b"], 3, c["hw"], c["hw"])),
+             u8(seed0 + 40 + i, (c["b"], 3, c["hw"], c["hw"])), ints(seed0 + 60 + i, (c["b"], 1), 6).to(torch.uint8))
+            for i in range(c["nb"])]
+
+
+def val_batches_reg(case, seed0=4000):
+    """BreastPathQ validate(): (input [n,3,H,W] u8, target [n] f32) (dataset.py eval contract)."""
+    c = CASES[case]
+    return [(u8(seed0 + i, (2, 3, c["hw"], c["hw"])), f32(seed0 + 50 + i, (2,))) for i in range(2)]
+
+
+def val_batches_cls(case, seed0, label):
+    c = CASES[case]
+    return [(u8(seed0 + i, (2, 3, c["hw"], c["hw"])), torch.full((2,), label, dtype=torch.int64))
+            for i in range(2)]

@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own train()/validate() on CPU.
+
+Run in the build container only (needs /root/reference):   python tests/golden/make_golden.py
+The reference's Python never travels; only the input/output vectors written here do.
+
+Aids (none of them reference source): the torchvision stand-in under _shims/ (torchvision
+0.8.1 is an un-vendored dependency, requirements.txt:416), MagicMock stubs for the reference's
+unused heavy imports, and a ``.cuda()`` no-op.  Weights come from oracle.model.init_state
+(numpy legacy RNG) loaded through ``load_state_dict`` -- exactly how the reference scripts
+load a checkpoint (eval_BreastPathQ_SSL_CR.py:394-402).
+"""
+import importlib
+import importlib.abc
+import importlib.machinery
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SSLCR_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "_shims"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+STUBS = ("cv2", "pingouin", "statsmodels", "albumentations", "h5py", "openslide", "skimage")
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path=None, target=None):
+        if name.split(".")[0] in STUBS:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+        return None
+
+    def create_module(self, spec):
+        m = mock.MagicMock(name=spec.name)
+        m.__path__ = []
+        m.__name__ = spec.name
+        m.__spec__ = spec
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+sys.meta_path.insert(0, _StubFinder())
+torch.Tensor.cuda = lambda self, *a, **k: self          # CPU run of a script written for CUDA
+torch.cuda.synchronize = lambda *a, **k: None
+
+from oracle import cases as C            # noqa: E402
+from oracle import model as OM           # noqa: E402
+
+torch.set_num_threads(8)
+torch.use_deterministic_algorithms(False)
+
+net = importlib.import_module("models.net")
+
+
+def build(kind_net, kind_cls, classes, seed=C.PARAM_SEED, rand_stats=False):
+    """reference modules with seeded weights."""
+    model = net.TripletNet_Finetune("resnet18") if kind_net == "finetune" else net.TripletNet("resnet18")
+    cls = net.FinetuneResNet(classes) if kind_cls == "finetune" else net.Classifier(768, classes)
+    sd = OM.init_state(seed, OM.net_param_specs(), random_running_stats=rand_stats)
+    model.load_state_dict(sd)
+    csd = OM.init_state(seed + 1, OM.classifier_param_specs("finetune" if kind_cls == "finetune" else "mlp", classes))
+    cls.load_state_dict(csd)
+    return model, cls
+
+
+def freeze(model, modules):
+    for idx, (_, prm) in enumerate(model.named_parameters()):
+        prm.requires_grad = idx >= modules
+
+
+def snapshot(prefix, model, cls, out):
+    """post-step student state: norms/sums of every tensor + a few full tensors/slices."""
+    names, l2, sm = [], [], []
+    for mod, pre in ((model, ""), (cls, "")):
+        for k, v in mod.state_dict().items():
+            if "num_batches" in k:
+                out[f"{prefix}/nbt/{k}"] = np.int64(v.item())
+                continue
+            names.append(k)
+            d = v.detach().double()
+            l2.append(float(d.norm()))
+            sm.append(float(d.sum()))
+    out[f"{prefix}/names"] = np.array(names)
+    out[f"{prefix}/l2"] = np.array(l2)
+    out[f"{prefix}/sum"] = np.array(sm)
+    sd = model.state_dict()
+    for k in ("model.bn1.weight", "model.bn1.running_mean", "model.bn1.running_var",
+              "model.layer2.0.downsample.1.running_var", "model.layer4.1.bn2.running_mean",
+              "model.layer4.1.bn2.bias", "fc.2.bias"):
+        out[f"{prefix}/t/{k}"] = sd[k].detach().numpy().copy()
+    out[f"{prefix}/t/model.conv1.weight[:2]"] = sd["model.conv1.weight"][:2].detach().numpy().copy()
+    out[f"{prefix}/t/model.layer4.1.conv2.weight[:1,:8]"] = sd["model.layer4.1.conv2.weight"][:1, :8].detach().numpy().copy()
+    out[f"{prefix}/t/fc.0.weight[:2]"] = sd["fc.0.weight"][:2].detach().numpy().copy()
+    for k, v in cls.state_dict().items():
+        out[f"{prefix}/t/{k}"] = v.detach().numpy().copy()
+
+
+def args_ns(**kw):
+    ns = types.SimpleNamespace(print_freq=1000, **kw)
+    return ns
+
+
+def gen_bpq_cr(name, out):
+    c = C.CASES[name]
+    m = importlib.import_module("eval_BreastPathQ_SSL_CR")
+    mt, ct = build("finetune", "finetune", 1, rand_stats=True)
+    ms, cs = build("finetune", "finetune", 1, rand_stats=True)
+    freeze(mt, 64)
+    freeze(ms, c["modules"])
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())),
+                           lr=c["lr"], betas=(0.9, 0.999), weight_decay=c["wd"])
+    ret = m.train(args_ns(lambda_u=c["lambda_u"]), mt, ms, ct, cs, C.labeled_batches(name),
+                  C.unlabeled_batches(name), opt, 1)
+    out[f"{name}/ret"] = np.array(ret[:3], dtype=np.float64)
+    out[f"{name}/feats"] = ret[3].numpy()
+    out[f"{name}/targets"] = ret[4].numpy()
+    snapshot(name, ms, cs, out)
+    val = m.validate(args_ns(), ms, cs, C.val_batches_reg(name), 1)
+    out[f"{name}/val"] = np.array([val], dtype=np.float64)
+
+
+def gen_cam_cr(name, out):
+    c = C.CASES[name]
+    m = importlib.import_module("eval_Camelyon_SSL_CR")
+    mt, ct = build("finetune", "finetune", 2, rand_stats=True)
+    ms, cs = build("finetune", "finetune", 2, rand_stats=True)
+    freeze(mt, 64)
+    freeze(ms, c["modules"])
+    opt = torch.optim.SGD(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())),
+                          lr=c["lr"], momentum=0.9, weight_decay=c["wd"], nesterov=True)
+    torch.manual_seed(777)                     # pins the reference's torch.randperm shuffles (:79-81)
+    ret = m.train(args_ns(lambda_u=c["lambda_u"], image_size=c["hw"]), mt, ms, ct, cs,
+                  C.labeled_batches_cls(name, 1000, 1), C.labeled_batches_cls(name, 1100, 0),
+                  C.unlabeled_batches(name, 2000), C.unlabeled_batches(name, 2100), opt, 1)
+    out[f"{name}/ret"] = np.array(ret[:4], dtype=np.float64)
+    out[f"{name}/feats"] = ret[4].numpy()
+    out[f"{name}/targets"] = ret[5].numpy()
+    snapshot(name, ms, cs, out)
+    torch.manual_seed(778)
+    val = m.validate(args_ns(), ms, cs, C.val_batches_cls(name, 4000, 1), C.val_batches_cls(name, 4100, 0), 1)
+    out[f"{name}/val"] = np.array(val, dtype=np.float64)
+
+
+def gen_rsp(name, out):
+    c = C.CASES[name]
+    m = importlib.import_module("pretrain_BreastPathQ")
+    from models.optimiser.RAdam.lookahead import Lookahead
+    model, cls = build("triplet", "mlp", 6)
+    crit = torch.nn.CrossEntropyLoss()
+    opt = torch.optim.SGD(list(model.parameters()) + list(cls.parameters()), lr=c["lr"], momentum=0.9,
+                          weight_decay=c["wd"], nesterov=True)
+    la = Lookahead(opt, la_steps=5, la_alpha=0.5)
+    a = args_ns(tile_h=c["hw"], tile_w=c["hw"])
+    ret = m.train(a, model, cls, C.rsp_batches(name), crit, opt, 1)
+    out[f"{name}/ret"] = np.array(ret[:2], dtype=np.float64)
+    out[f"{name}/feats"] = ret[2].numpy()
+    out[f"{name}/targets"] = ret[3].numpy()
+    snapshot(name, model, cls, out)
+    val = m.validate(a, model, cls, C.rsp_batches(name, 3500), crit, 1)
+    out[f"{name}/val"] = np.array(val, dtype=np.float64)
+    # G7: the per-epoch "scheduler.step()" = Lookahead.step() with the stale grads (:293), 5 calls
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for _ in range(5):
+            la.step()
+    snapshot(name + "/la5", model, cls, out)
+
+
+def gen_cam_sup(name, out):
+    c = C.CASES[name]
+    m = importlib.import_module("eval_Camelyon_SSL")
+    ms, cs = build("finetune", "finetune", 2)
+    opt = torch.optim.SGD(list(ms.parameters()) + list(cs.parameters()), lr=c["lr"], momentum=0.9,
+                          weight_decay=c["wd"], nesterov=True)
+    torch.manual_seed(779)
+    ret = m.train(args_ns(image_size=c["hw"]), ms, cs, C.labeled_batches_cls(name, 1000, 1),
+                  C.labeled_batches_cls(name, 1100, 0), opt, 1)
+    out[f"{name}/ret"] = np.array(ret[:2], dtype=np.float64)
+    out[f"{name}/feats"] = ret[2].numpy()
+    out[f"{name}/targets"] = ret[3].numpy()
+    snapshot(name, ms, cs, out)
+
+
+def gen_bpq_sup(name, out):
+    c = C.CASES[name]
+    m = importlib.import_module("eval_BreastPathQ_SSL")
+    ms, cs = build("finetune", "finetune", 1)
+    opt = torch.optim.Adam(list(ms.parameters()) + list(cs.parameters()), lr=c["lr"], betas=(0.9, 0.999),
+                           weight_decay=c["wd"])
+    ret = m.train(args_ns(image_size=c["hw"]), ms, cs, C.labeled_batches(name), torch.nn.MSELoss(), opt, 1)
+    out[f"{name}/ret"] = np.array(ret[:1], dtype=np.float64)
+    out[f"{name}/feats"] = ret[1].numpy()
+    out[f"{name}/targets"] = ret[2].numpy()
+    snapshot(name, ms, cs, out)
+
+
+def gen_stages(out):
+    """G3: per-stage activations of the reference TripletNet_Finetune backbone, N=2, 64x64."""
+    for mode in ("eval", "train"):
+        model, _ = build("finetune", "finetune", 1, rand_stats=True)
+        model.train(mode == "train")
+        taps = {}
+        bb = model.model
+        hooks = [bb.maxpool.register_forward_hook(lambda m, i, o: taps.__setitem__("stem", o))]
+        for ln in ("layer1", "layer2", "layer3", "layer4"):
+            for bi in (0, 1):
+                hooks.append(getattr(bb, ln)[bi].register_forward_hook(
+                    lambda m, i, o, key=f"{ln}.{bi}": taps.__setitem__(key, o)))
+        x = C.u8(5000, (2, 3, 64, 64)).float()
+        with torch.no_grad():
+            feats = model(x)
+        for k, v in taps.items():
+            out[f"stages/{mode}/{k}"] = v.numpy().copy()
+        out[f"stages/{mode}/feats"] = feats.numpy().copy()
+        if mode == "train":
+            sd = model.state_dict()
+            for k in ("model.bn1.running_mean", "model.bn1.running_var", "model.layer3.0.downsample.1.running_mean",
+                      "model.layer4.1.bn2.running_var"):
+                out[f"stages/train/{k}"] = sd[k].numpy().copy()
+            out["stages/train/nbt"] = np.int64(sd["model.bn1.num_batches_tracked"].item())
+
+
+def main():
+    gens = {"bpq_cr_f60": gen_bpq_cr, "bpq_cr_f0": gen_bpq_cr, "cam_cr_f60": gen_cam_cr, "cam_cr_f0": gen_cam_cr,
+            "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup}
+    only = sys.argv[1:]
+    for name, fn in gens.items():
+        if only and name not in only:
+            continue
+        out = {}
+        fn(name, out)
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+        print("wrote", name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if "/ret" in k or "/val" in k},
+              out[f"{name}/ret"])
+    if not only or "stages" in only:
+        out = {}
+        gen_stages(out)
+        np.savez_compressed(os.path.join(HERE, "stages.npz"), **out)
+        print("wrote stages")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,139 @@
+"""Pin the CPU oracle (oracle/) against the golden vectors captured from the REFERENCE's own
+train()/validate() (tests/golden/make_golden.py).  CPU only."""
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import epochs as E
+from oracle import model as OM
+from oracle import steps as S
+
+from _util import check_snapshot, load_golden, merged, oracle_state, rel_err, snapshot_dict
+
+RT = 2e-4      # oracle and reference run the same torch CPU ops; slack covers summation order
+
+
+def _student_teacher(classes, modules):
+    pn_s, bn_s, pc_s = oracle_state("finetune", classes, True)
+    pn_t, bn_t, pc_t = oracle_state("finetune", classes, True)
+    S.apply_freeze(pn_s, modules)
+    for v in pc_s.values():
+        v.requires_grad_(True)
+    return merged(pn_s, pc_s), bn_s, merged(pn_t, pc_t), bn_t
+
+
+@pytest.mark.parametrize("faithful", [True, False])
+@pytest.mark.parametrize("name", ["bpq_cr_f60", "bpq_cr_f0"])
+def test_bpq_cr(name, faithful):
+    c = C.CASES[name]
+    g = load_golden(name)
+    ps, bs, pt, bt = _student_teacher(1, c["modules"])
+    opt = S.Adam(ps.values(), c["lr"], (0.9, 0.999), 1e-8, c["wd"])
+    ret = E.bpq_cr_train(ps, bs, pt, bt, opt, C.labeled_batches(name), C.unlabeled_batches(name),
+                         c["lambda_u"], faithful)
+    rt = RT if faithful else 2e-3
+    for i in range(3):
+        assert abs(ret[i] - g[f"{name}/ret"][i]) <= rt * abs(g[f"{name}/ret"][i])
+    assert rel_err(ret[3], g[f"{name}/feats"]) < rt
+    assert torch.equal(ret[4], torch.from_numpy(g[f"{name}/targets"]))
+    check_snapshot(g, name, snapshot_dict(ps, bs), rt)
+    val = E.bpq_cr_validate(ps, bs, C.val_batches_reg(name), faithful)
+    assert abs(val - g[f"{name}/val"][0]) <= rt * abs(g[f"{name}/val"][0])
+
+
+@pytest.mark.parametrize("faithful", [True, False])
+@pytest.mark.parametrize("name", ["cam_cr_f60", "cam_cr_f0"])
+def test_cam_cr(name, faithful):
+    c = C.CASES[name]
+    g = load_golden(name)
+    ps, bs, pt, bt = _student_teacher(2, c["modules"])
+    opt = S.SGDNesterov(ps.values(), c["lr"], 0.9, c["wd"])
+    torch.manual_seed(777)
+    ret = E.cam_cr_train(ps, bs, pt, bt, opt, C.labeled_batches_cls(name, 1000, 1),
+                         C.labeled_batches_cls(name, 1100, 0), C.unlabeled_batches(name, 2000),
+                         C.unlabeled_batches(name, 2100), c["lambda_u"], c["hw"], faithful)
+    rt = RT if faithful else 2e-3
+    for i in range(4):
+        assert abs(ret[i] - g[f"{name}/ret"][i]) <= rt * abs(g[f"{name}/ret"][i]) + 1e-9
+    assert rel_err(ret[4], g[f"{name}/feats"]) < rt
+    assert torch.equal(ret[5], torch.from_numpy(g[f"{name}/targets"]))
+    check_snapshot(g, name, snapshot_dict(ps, bs), rt)
+    torch.manual_seed(778)
+    val = E.cam_cr_validate(ps, bs, C.val_batches_cls(name, 4000, 1), C.val_batches_cls(name, 4100, 0), faithful)
+    assert abs(val[0] - g[f"{name}/val"][0]) <= rt * abs(g[f"{name}/val"][0])
+    assert val[1] == g[f"{name}/val"][1]
+
+
+def test_rsp_and_lookahead():
+    name = "rsp"
+    c = C.CASES[name]
+    g = load_golden(name)
+    pn, bn, pc = oracle_state("mlp", 6, False)
+    p = merged(pn, pc)
+    for v in p.values():
+        v.requires_grad_(True)
+    opt = S.SGDNesterov(p.values(), c["lr"], 0.9, c["wd"])
+    la = S.Lookahead(opt, 5, 0.5)
+    ret = E.rsp_epoch(p, bn, opt, C.rsp_batches(name), c["hw"], True)
+    assert abs(ret[0] - g["rsp/ret"][0]) <= RT * g["rsp/ret"][0]
+    assert ret[1] == g["rsp/ret"][1]
+    assert rel_err(ret[2], g["rsp/feats"]) < RT
+    assert torch.equal(ret[3], torch.from_numpy(g["rsp/targets"]))
+    check_snapshot(g, "rsp", snapshot_dict(p, bn), RT)
+    val = E.rsp_epoch(p, bn, None, C.rsp_batches(name, 3500), c["hw"], False)
+    assert abs(val[0] - g["rsp/val"][0]) <= RT * g["rsp/val"][0]
+    assert val[1] == g["rsp/val"][1]
+    for _ in range(5):          # pretrain_BreastPathQ.py:293 -- Lookahead stepped with stale grads
+        la.step()
+    check_snapshot(g, "rsp/la5", snapshot_dict(p, bn), RT)
+
+
+def test_supervised():
+    name = "cam_sup"
+    c = C.CASES[name]
+    g = load_golden(name)
+    pn, bn, pc = oracle_state("finetune", 2, False)
+    p = merged(pn, pc)
+    for v in p.values():
+        v.requires_grad_(True)
+    opt = S.SGDNesterov(p.values(), c["lr"], 0.9, c["wd"])
+    torch.manual_seed(779)
+    ret = E.cam_sup_train(p, bn, opt, C.labeled_batches_cls(name, 1000, 1), C.labeled_batches_cls(name, 1100, 0), c["hw"])
+    assert abs(ret[0] - g[f"{name}/ret"][0]) <= RT * g[f"{name}/ret"][0]
+    assert ret[1] == g[f"{name}/ret"][1]
+    assert rel_err(ret[2], g[f"{name}/feats"]) < RT
+    check_snapshot(g, name, snapshot_dict(p, bn), RT)
+
+    name = "bpq_sup"
+    c = C.CASES[name]
+    g = load_golden(name)
+    pn, bn, pc = oracle_state("finetune", 1, False)
+    p = merged(pn, pc)
+    for v in p.values():
+        v.requires_grad_(True)
+    opt = S.Adam(p.values(), c["lr"], (0.9, 0.999), 1e-8, c["wd"])
+    ret = E.bpq_sup_train(p, bn, opt, C.labeled_batches(name), c["hw"])
+    assert abs(ret[0] - g[f"{name}/ret"][0]) <= RT * g[f"{name}/ret"][0]
+    assert rel_err(ret[1], g[f"{name}/feats"]) < RT
+    check_snapshot(g, name, snapshot_dict(p, bn), RT)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_stage_activations(mode):
+    g = load_golden("stages")
+    pn, bn, _ = oracle_state("finetune", 1, True)
+    x = C.u8(5000, (2, 3, 64, 64)).float()
+    taps = {}
+    with torch.no_grad():
+        e = OM.backbone_forward(pn, bn, x, mode == "train", taps=taps)
+    for k, v in taps.items():
+        assert rel_err(v, g[f"stages/{mode}/{k}"]) < 1e-5, k
+    bn2 = {k: v.clone() for k, v in oracle_state("finetune", 1, True)[1].items()}
+    with torch.no_grad():
+        feats = OM.finetune_forward(pn, bn2, x, mode == "train", faithful=False)
+    assert rel_err(feats, g[f"stages/{mode}/feats"]) < 1e-5
+    if mode == "train":     # the x3 running-stat replay of TripletNet_Finetune (models/net.py:88-90)
+        for k in ("model.bn1.running_mean", "model.bn1.running_var", "model.layer3.0.downsample.1.running_mean",
+                  "model.layer4.1.bn2.running_var"):
+            assert rel_err(bn2[k], g[f"stages/train/{k}"]) < 1e-5, k
+        assert int(bn2["model.bn1.num_batches_tracked"]) == int(g["stages/train/nbt"]) == 3
