@@ -1,0 +1,173 @@
+/* sslcr.h -- C ABI of the MI355X (gfx950) engine for the SSL_CR_Histo ResNet18 step path.
+ *
+ * The reference (srinidhiPY/SSL_CR_Histo) is pure Python on torch/cuDNN and has NO FFI of its own; the seam
+ * this library plugs into is "the torch ops behind models/net.py + the step body of train()/validate()".
+ * Each entry point below names the reference code it replaces.  Conventions:
+ *   - return 0 on success, negative on error; sslcr_last_error() gives the message (thread local);
+ *     no C++ exception crosses this boundary;
+ *   - every pointer is a DEVICE pointer owned by the caller unless stated otherwise; the engine never frees it;
+ *   - `stream` is the caller's hipStream_t (torch.cuda.current_stream().cuda_stream); all calls are asynchronous;
+ *   - activations are NHWC, conv weights [K][R][S][C] ("KRSC"), dtype 0 = fp32 (exact-parity mode,
+ *     v_mfma_f32_16x16x4_f32), 1 = bf16 storage with fp32 accumulate (v_mfma_f32_16x16x32_bf16);
+ *   - one sslcr_ctx per process per device, not thread safe (single training thread, like the reference).
+ */
+#ifndef SSLCR_H_
+#define SSLCR_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSLCR_F32 0
+#define SSLCR_BF16 1
+
+int sslcr_version(void);
+const char* sslcr_last_error(void);
+
+/* ---- conv2d forward / dgrad (replaces nn.Conv2d inside torchvision resnet18: models/net.py:32,77;
+ *      BasicBlock convs K2-K4 of SURVEY 2b, and their autograd dgrad K13) */
+typedef struct sslcr_conv_desc {
+  const void* x;          /* gathered tensor, NHWC [N][H][W][C] */
+  const void* w;          /* [K][R][S][C] */
+  void* y;                /* NHWC [N][OH][OW][K] */
+  const float* in_scale;  /* [C] or NULL: prologue x*scale+shift (+relu) on in-bounds pixels (producer BN fused in the load) */
+  const float* in_shift;
+  const float* bias;      /* [K] or NULL */
+  const void* residual;   /* like y, or NULL */
+  float* stats;           /* [sslcr_conv2d_partial_rows][2][K] fp32 or NULL: per-channel (sum, sumsq) partials */
+  int N, H, W, C, K, R, S, stride, pad;
+  int PH, PW;             /* pixel space the GEMM M dimension enumerates */
+  int OH, OW, osh;        /* physical output dims; pixel (ph,pw) is stored at (ph*osh, pw*osh) */
+  int transposed;         /* 0: src = p*stride-pad+r ; 1 (dgrad): src = (p+pad-r)/stride when divisible */
+  int in_relu, relu, accumulate;
+} sslcr_conv_desc;
+int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream);
+int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d);
+
+/* ---- conv2d weight gradient (autograd wgrad of the same convs) */
+typedef struct sslcr_wgrad_desc {
+  const void* x;          /* conv input NHWC [N][H][W][C] (the raw producer output when in_scale != NULL) */
+  const void* dy;         /* NHWC [N][OH][OW][K] */
+  float* dw;              /* [K][R][S][C] fp32, ACCUMULATED into */
+  const float* in_scale;
+  const float* in_shift;
+  int in_relu;
+  int N, H, W, C, K, R, S, stride, pad, OH, OW;
+} sslcr_wgrad_desc;
+int sslcr_conv2d_wgrad(int dtype, const sslcr_wgrad_desc* d, void* stream);
+
+/* diagnostics: lane l of one wave performs ds_read_b64_tr_b16 at byte_addr[l] of a 2 KiB LDS copy of `in`; out[l][0..3] */
+int sslcr_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, void* stream);
+
+/* ---- stem: uint8/fp32 NCHW ingestion fused with conv1 7x7/2 (eval_BreastPathQ_SSL_CR.py:68-74 .float()/reshape
+ *      + resnet18.conv1) */
+typedef struct sslcr_stem_desc {
+  const void* x;          /* NCHW [N][3][H][W], uint8 (in_f32=0) or fp32 (in_f32=1), values 0..255 un-normalised */
+  const void* w;          /* packed [64][7][8][4] (s=7 and c=3 are zero) -- see sslcr_pack_stem */
+  void* y;                /* NHWC [N][OH][OW][64] */
+  const float* bias;      /* [64] or NULL */
+  float* stats;           /* [sslcr_stem_partial_rows][2][64] or NULL */
+  int N, H, W, OH, OW, in_f32, relu;
+} sslcr_stem_desc;
+int sslcr_stem_conv(int dtype, const sslcr_stem_desc* d, void* stream);
+int sslcr_stem_partial_rows(const sslcr_stem_desc* d);
+typedef struct sslcr_stem_wgrad_desc {
+  const void* x; const void* dy;
+  float* dw;              /* [64][3][7][7] fp32 (PyTorch layout), accumulated */
+  int N, H, W, OH, OW, in_f32;
+} sslcr_stem_wgrad_desc;
+int sslcr_stem_wgrad(int dtype, const sslcr_stem_wgrad_desc* d, void* stream);
+
+/* ---- BatchNorm2d (train: batch stats, running update; replaces nn.BatchNorm2d x20) */
+typedef struct sslcr_bn_finalize_desc {
+  const float* partials;  /* [rows][2][C] */
+  int rows, C;
+  double count;           /* elements per channel (global) */
+  const float* gamma; const float* beta;
+  float* scale; float* shift; float* mean; float* invstd;
+  float* running_mean; float* running_var; int64_t* num_batches_tracked;   /* may be NULL */
+  float momentum, eps; int replay;    /* replay=3 reproduces TripletNet_Finetune's 3 identical passes (models/net.py:88-90) */
+  double* sums_out;       /* [2][C]: only reduce the partial rows (sharded runs all-reduce this, then call again with sums_in) */
+  const double* sums_in;
+  double* stage;          /* workspace [32][2][C] doubles for the two-stage row reduction */
+} sslcr_bn_finalize_desc;
+int sslcr_bn_finalize(const sslcr_bn_finalize_desc* d, void* stream);
+
+typedef struct sslcr_bn_act_desc {      /* y = relu(x*scale+shift [+ res*rscale+rshift | + res])  (K5 apply, K6, K7) */
+  const void* x; const float* scale; const float* shift;
+  const void* res; const float* rscale; const float* rshift;
+  void* y; size_t pixels; int C; int relu;
+} sslcr_bn_act_desc;
+int sslcr_bn_act(int dtype, const sslcr_bn_act_desc* d, void* stream);
+
+typedef struct sslcr_pool_fwd_desc {    /* maxpool3x3/2 pad 1 of relu(bn(x))   (K8) */
+  const void* x; const float* scale; const float* shift; void* y; uint8_t* argmax; int N, H, W, C, OH, OW;
+} sslcr_pool_fwd_desc;
+int sslcr_bn_relu_maxpool(int dtype, const sslcr_pool_fwd_desc* d, void* stream);
+typedef struct sslcr_pool_bwd_desc {
+  const void* dy; const uint8_t* argmax; const void* x; const float* scale; const float* shift; void* dx; int N, H, W, C, OH, OW;
+} sslcr_pool_bwd_desc;
+int sslcr_maxpool_relu_bwd(int dtype, const sslcr_pool_bwd_desc* d, void* stream);
+
+int sslcr_avgpool_fwd(int dtype, const void* x, float* y, int N, int HW, int C, void* stream);          /* K9 */
+int sslcr_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C, void* stream);
+
+typedef struct sslcr_bn_bwd_desc {
+  const void* dy; const void* x; const void* yact;
+  const float* scale; const float* shift; const float* mean; const float* invstd;
+  double* sums;           /* [2][C], zeroed by the caller before reduce */
+  void* dx; void* gout;
+  size_t pixels; int C; int relu_from_x; double count;
+} sslcr_bn_bwd_desc;
+int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
+int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
+int sslcr_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, void* stream);
+
+/* ---- heads and losses (models/net.py:12-15,35-36,111; F.mse_loss / F.cross_entropy at
+ *      eval_BreastPathQ_SSL_CR.py:92-95, eval_Camelyon_SSL_CR.py:110-116, pretrain_BreastPathQ.py:56) */
+int sslcr_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu, void* stream);
+int sslcr_linear_bwd(const float* x, const float* w, const float* dy, const float* yact, float* dx, float* dw, float* db,
+                     int M, int N, int K, int dx_accumulate, float* scratch, void* stream);
+typedef struct sslcr_loss_desc {
+  int kind;               /* 0 mse+mse (BreastPathQ CR) ; 1 ce + hard-pseudo-label ce (Camelyon/Kather CR) ; 2 ce ; 3 mse */
+  const float* logits; const float* logits_t;
+  const float* target_f; const int64_t* target_i;
+  float* dlogits;
+  float* out;             /* [4]: loss, loss_x, loss_u, #correct */
+  int nx, nu, C; float lambda_u;
+  float inv_nx_global, inv_nu_global;
+} sslcr_loss_desc;
+int sslcr_loss(const sslcr_loss_desc* d, void* stream);
+
+/* ---- optimizers (torch.optim.Adam / SGD nesterov as the reference configures them,
+ *      eval_BreastPathQ_SSL_CR.py:481, eval_Camelyon_SSL_CR.py:514, pretrain_BreastPathQ.py:245; Lookahead lookahead.py:81-106) */
+typedef struct sslcr_tensor_desc {
+  float* p; float* g; float* s1; float* s2;
+  int n;
+  int K, C, RS;           /* conv weight: g is [K][RS][C] while p/s1/s2 are [K][C][RS] ; K=0: same layout */
+} sslcr_tensor_desc;
+typedef struct sslcr_opt_desc {
+  int kind;               /* 0 adam, 1 sgd-nesterov */
+  float lr, beta1, beta2, eps, wd, momentum;
+  float bc1, bc2;
+  int first_step;
+  float grad_scale;
+} sslcr_opt_desc;
+int sslcr_optimizer_step(const sslcr_tensor_desc* device_descs, int ntensors, int max_n, const sslcr_opt_desc* o, void* stream);
+int sslcr_axpby(float* p, float* q, size_t n, float alpha, int copy_back, void* stream);
+int sslcr_fill(float* p, size_t n, float v, void* stream);
+
+typedef struct sslcr_pack_desc {
+  const float* w; void* w_fwd; void* w_dgrad;
+  const float* gamma; const float* beta; const float* rmean; const float* rvar; float eps; float* bias_out;
+  int K, C, R, S;
+} sslcr_pack_desc;
+int sslcr_pack_conv(int dtype, const sslcr_pack_desc* d, void* stream);
+int sslcr_pack_stem(int dtype, const sslcr_pack_desc* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSLCR_H_ */

@@ -1,0 +1,411 @@
+// BatchNorm statistics/finalize, fused BN(+residual)+ReLU, max/avg pooling and BN backward for NHWC tensors.
+// All HBM-bound: 16-byte vector accesses, channel-contiguous, grid-stride.  Replaces nn.BatchNorm2d / ReLU /
+// residual add / MaxPool2d / AdaptiveAvgPool2d of torchvision resnet18 and their autograd (K13).
+#include "kernels.hpp"
+
+namespace sslcr {
+
+// ------------------------------------------------------------------ statistics: partial rows -> sums -> scale/shift
+// stage 1: grid (C/32, SPLITS); block 256 = 32 channels x 8 row lanes
+__global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const float* __restrict__ part, int rows, int C, double* __restrict__ out, int splits) {
+  __shared__ double sm[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int rl = threadIdx.x >> 5;
+  const int per = (rows + splits - 1) / splits;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s = 0.0, ss = 0.0;
+  if (c < C) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      const float* p = part + (size_t)r * 2 * C;
+      s += (double)p[c];
+      ss += (double)p[C + c];
+    }
+  }
+  sm[0][rl][threadIdx.x & 31] = s;
+  sm[1][rl][threadIdx.x & 31] = ss;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int which = threadIdx.x >> 5, cc = threadIdx.x & 31;
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += sm[which][i][cc];
+    const int ch = blockIdx.x * 32 + cc;
+    if (ch < C) out[((size_t)blockIdx.y * 2 + which) * C + ch] = t;
+  }
+}
+
+// stage 2 (+ finalize): one thread per channel
+__global__ void bn_finalize_kernel(const double* __restrict__ stage, int splits, const BnFinalizeArgs a) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= a.C) return;
+  double s = 0.0, ss = 0.0;
+  if (a.sums_in) {
+    s = a.sums_in[c];
+    ss = a.sums_in[a.C + c];
+  } else {
+    for (int i = 0; i < splits; ++i) {
+      s += stage[((size_t)i * 2) * a.C + c];
+      ss += stage[((size_t)i * 2 + 1) * a.C + c];
+    }
+  }
+  if (a.sums_out) {
+    a.sums_out[c] = s;
+    a.sums_out[a.C + c] = ss;
+    return;
+  }
+  const double mean = s / a.count;
+  double var = ss / a.count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)a.eps);
+  const double sc = (double)a.gamma[c] * invstd;
+  a.scale[c] = (float)sc;
+  a.shift[c] = (float)((double)a.beta[c] - mean * sc);
+  if (a.mean) a.mean[c] = (float)mean;
+  if (a.invstd) a.invstd[c] = (float)invstd;
+  if (a.running_mean) {
+    const double unb = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+    float rm = a.running_mean[c], rv = a.running_var[c];
+    for (int i = 0; i < a.replay; ++i) {       // same arithmetic as `replay` sequential nn.BatchNorm2d updates
+      rm = (1.f - a.momentum) * rm + a.momentum * (float)mean;
+      rv = (1.f - a.momentum) * rv + a.momentum * (float)unb;
+    }
+    a.running_mean[c] = rm;
+    a.running_var[c] = rv;
+    if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += a.replay;
+  }
+}
+
+hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
+  constexpr int SPLITS = 32;
+  double* stage = a.stage;
+  int splits = 0;
+  if (!a.sums_in) {
+    splits = a.rows >= 64 * SPLITS ? SPLITS : 1;
+    hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(cdiv(a.C, 32), splits), dim3(256), 0, st, a.partials, a.rows, a.C, stage, splits);
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a.C, 64)), dim3(64), 0, st, stage, splits, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ y = relu(bn(x) [+ bn(res) | + res])
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = a.C / EPC;
+  const size_t total = a.pixels * cols;
+  const char* x = reinterpret_cast<const char*>(a.x);
+  const char* r = reinterpret_cast<const char*>(a.res);
+  char* y = reinterpret_cast<char*>(a.y);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % cols) * EPC;
+    float f[EPC], g[EPC];
+    Elem<T>::unpack(ld16(x + i * 16), f);
+    if (r) Elem<T>::unpack(ld16(r + i * 16), g);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float v = fmaf(f[e], a.scale[cb + e], a.shift[cb + e]);
+      if (r) v += a.rscale ? fmaf(g[e], a.rscale[cb + e], a.rshift[cb + e]) : g[e];
+      f[e] = a.relu ? fmaxf(v, 0.f) : v;
+    }
+    st16(y + i * 16, Elem<T>::pack(f));
+  }
+}
+
+static inline int ew_grid(size_t work_items) {
+  size_t b = (work_items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 256 * 16 ? 256 * 16 : b));
+}
+
+hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st) {
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(ew_grid(a.pixels * (a.C / 8))), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_grid(a.pixels * (a.C / 4))), dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ stem: maxpool3x3/2 p1 over relu(bn(x)), with argmax
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = a.C / EPC;
+  const size_t total = (size_t)a.N * a.OH * a.OW * cols;
+  const char* x = reinterpret_cast<const char*>(a.x);
+  char* y = reinterpret_cast<char*>(a.y);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int col = (int)(i % cols);
+    size_t pix = i / cols;
+    const int ow = (int)(pix % a.OW);
+    pix /= a.OW;
+    const int oh = (int)(pix % a.OH);
+    const int n = (int)(pix / a.OH);
+    const int cb = col * EPC;
+    float best[EPC];
+    int arg[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+#pragma unroll
+    for (int wi = 0; wi < 9; ++wi) {
+      const int h = 2 * oh - 1 + wi / 3, w = 2 * ow - 1 + wi % 3;
+      if (h < 0 || w < 0 || h >= a.H || w >= a.W) continue;
+      float f[EPC];
+      Elem<T>::unpack(ld16(x + (((size_t)n * a.H + h) * a.W + w) * a.C * sizeof(T) + (size_t)col * 16), f);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        float v = fmaxf(fmaf(f[e], a.scale[cb + e], a.shift[cb + e]), 0.f);
+        if (v > best[e]) { best[e] = v; arg[e] = wi; }
+      }
+    }
+    st16(y + i * 16, Elem<T>::pack(best));
+    if (a.argmax) {
+      uint8_t* ap = a.argmax + i * EPC;
+      if (EPC == 8) {
+        uint32_t lo = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+        uint32_t hi = arg[4 % EPC] | (arg[5 % EPC] << 8) | (arg[6 % EPC] << 16) | (arg[7 % EPC] << 24);
+        *reinterpret_cast<u32x2_t*>(ap) = u32x2_t{lo, hi};
+      } else {
+        *reinterpret_cast<uint32_t*>(ap) = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+      }
+    }
+  }
+}
+
+hipError_t launch_bn_relu_maxpool(int dtype, const PoolFwdArgs& a, hipStream_t st) {
+  size_t px = (size_t)a.N * a.OH * a.OW;
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(ew_grid(px * (a.C / 8))), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(px * (a.C / 4))), dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+// dx[n,h,w,c] = (bn(x)>0) * sum_{windows containing (h,w) whose argmax is (h,w)} dy[window]
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const PoolBwdArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = a.C / EPC;
+  const size_t total = (size_t)a.N * a.H * a.W * cols;
+  const char* x = reinterpret_cast<const char*>(a.x);
+  const char* dy = reinterpret_cast<const char*>(a.dy);
+  char* dx = reinterpret_cast<char*>(a.dx);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int col = (int)(i % cols);
+    size_t pix = i / cols;
+    const int w = (int)(pix % a.W);
+    pix /= a.W;
+    const int h = (int)(pix % a.H);
+    const int n = (int)(pix / a.H);
+    const int cb = col * EPC;
+    float acc[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+    const int oh0 = h >> 1, ow0 = w >> 1;          // candidates: oh in {h/2, (h+1)/2}
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh) {
+      const int oh = oh0 + dh;
+      const int wi_h = h - (2 * oh - 1);
+      if (oh >= a.OH || wi_h < 0 || wi_h > 2 || (dh == 1 && ((h & 1) == 0))) continue;
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const int ow = ow0 + dw;
+        const int wi_w = w - (2 * ow - 1);
+        if (ow >= a.OW || wi_w < 0 || wi_w > 2 || (dw == 1 && ((w & 1) == 0))) continue;
+        const int code = wi_h * 3 + wi_w;
+        const size_t o = (((size_t)n * a.OH + oh) * a.OW + ow) * cols + col;
+        float g[EPC];
+        Elem<T>::unpack(ld16(dy + o * 16), g);
+        const uint8_t* ap = a.argmax + o * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          if (ap[e] == code) acc[e] += g[e];
+      }
+    }
+    float f[EPC];
+    Elem<T>::unpack(ld16(x + i * 16), f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (!(fmaf(f[e], a.scale[cb + e], a.shift[cb + e]) > 0.f)) acc[e] = 0.f;
+    st16(dx + i * 16, Elem<T>::pack(acc));
+  }
+}
+
+hipError_t launch_maxpool_relu_bwd(int dtype, const PoolBwdArgs& a, hipStream_t st) {
+  size_t px = (size_t)a.N * a.H * a.W;
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(maxpool_relu_bwd_kernel<bf16_t>, dim3(ew_grid(px * (a.C / 8))), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(maxpool_relu_bwd_kernel<float>, dim3(ew_grid(px * (a.C / 4))), dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ global average pool
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const void* xv, float* y, int N, int HW, int C) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = C / EPC;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * cols) return;
+  const int n = i / cols, col = i - n * cols;
+  const char* x = reinterpret_cast<const char*>(xv) + ((size_t)n * HW * C) * sizeof(T) + (size_t)col * 16;
+  float acc[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) acc[e] = 0.f;
+  for (int p = 0; p < HW; ++p) {
+    float f[EPC];
+    Elem<T>::unpack(ld16(x + (size_t)p * C * sizeof(T)), f);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) acc[e] += f[e];
+  }
+  const float inv = 1.f / (float)HW;
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) y[(size_t)n * C + col * EPC + e] = acc[e] * inv;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* dy, void* dxv, int N, int HW, int C) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = C / EPC;
+  const size_t total = (size_t)N * HW * cols;
+  char* dx = reinterpret_cast<char*>(dxv);
+  const float inv = 1.f / (float)HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int col = (int)(i % cols);
+    const int n = (int)(i / ((size_t)HW * cols));
+    float f[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) f[e] = dy[(size_t)n * C + col * EPC + e] * inv;
+    st16(dx + i * 16, Elem<T>::pack(f));
+  }
+}
+
+hipError_t launch_avgpool_fwd(int dtype, const void* x, float* y, int N, int HW, int C, hipStream_t st) {
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(cdiv(N * (C / 8), 256)), dim3(256), 0, st, x, y, N, HW, C);
+  } else {
+    hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(cdiv(N * (C / 4), 256)), dim3(256), 0, st, x, y, N, HW, C);
+  }
+  return hipGetLastError();
+}
+hipError_t launch_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C, hipStream_t st) {
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(ew_grid((size_t)N * HW * (C / 8))), dim3(256), 0, st, dy, dx, N, HW, C);
+  } else {
+    hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(ew_grid((size_t)N * HW * (C / 4))), dim3(256), 0, st, dy, dx, N, HW, C);
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ BatchNorm backward
+template <typename T>
+__device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, int cb, float* g, float* xf) {
+  constexpr int EPC = Elem<T>::EPC;
+  Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.dy) + i * 16), g);
+  Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.x) + i * 16), xf);
+  if (a.yact) {
+    float ya[EPC];
+    Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.yact) + i * 16), ya);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (!(ya[e] > 0.f)) g[e] = 0.f;
+  } else if (a.relu_from_x) {
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (!(fmaf(xf[e], a.scale[cb + e], a.shift[cb + e]) > 0.f)) g[e] = 0.f;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  __shared__ float sm[256][2 * EPC + 1];
+  const int cols = a.C / EPC;                 // <= 256 and a power of two for resnet18
+  const int rpp = 256 / cols;                 // pixel rows per pass
+  const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+  const int cb = col * EPC;
+  float s0[EPC], s1[EPC], mean[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { s0[e] = 0.f; s1[e] = 0.f; mean[e] = a.mean[cb + e]; }
+  if (rl < rpp) {
+    for (size_t p = (size_t)blockIdx.x * rpp + rl; p < a.pixels; p += (size_t)gridDim.x * rpp) {
+      float g[EPC], xf[EPC];
+      bn_bwd_g<T>(a, p * cols + col, cb, g, xf);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { s0[e] += g[e]; s1[e] = fmaf(g[e], xf[e] - mean[e], s1[e]); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { sm[threadIdx.x][e] = s0[e]; sm[threadIdx.x][EPC + e] = s1[e]; }
+  __syncthreads();
+  // thread t < cols*2*EPC: (col, which/e) sums over rl
+  for (int t = threadIdx.x; t < cols * 2 * EPC; t += 256) {
+    const int cc = t / (2 * EPC), q = t - cc * 2 * EPC;
+    double acc = 0.0;
+    for (int r = 0; r < rpp; ++r) acc += (double)sm[r * cols + cc][q];
+    const int which = q / EPC, e = q - which * EPC;
+    atomicAdd(&a.sums[(size_t)which * a.C + cc * EPC + e], acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = a.C / EPC;
+  const size_t total = a.pixels * cols;
+  const float invM = (float)(1.0 / a.count);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cb = (int)(i % cols) * EPC;
+    float g[EPC], xf[EPC], d[EPC];
+    bn_bwd_g<T>(a, i, cb, g, xf);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = cb + e;
+      const float is = a.invstd[c];
+      const float m0 = (float)a.sums[c] * invM, m1 = (float)a.sums[a.C + c] * invM;
+      d[e] = a.scale[c] * (g[e] - m0 - (xf[e] - a.mean[c]) * is * is * m1);
+    }
+    st16(reinterpret_cast<char*>(a.dx) + i * 16, Elem<T>::pack(d));
+    if (a.gout) st16(reinterpret_cast<char*>(a.gout) + i * 16, Elem<T>::pack(g));
+  }
+}
+
+hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
+  const int epc = dtype == DT_BF16 ? 8 : 4;
+  const int cols = a.C / epc;
+  if (cols > 256 || (256 % cols) != 0) return hipErrorInvalidValue;
+  const int rpp = 256 / cols;
+  size_t blocks = (a.pixels + rpp - 1) / rpp;
+  blocks = (blocks + 7) / 8;                              // >= 8 passes per block
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st) {
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(a.pixels * (a.C / 8))), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(a.pixels * (a.C / 4))), dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+__global__ void bn_param_grads_kernel(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dgamma[c] += (float)(sums[C + c] * (double)invstd[c]);
+  dbeta[c] += (float)sums[c];
+}
+hipError_t launch_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, hipStream_t st) {
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, invstd, dgamma, dbeta, C);
+  return hipGetLastError();
+}
+
+}  // namespace sslcr

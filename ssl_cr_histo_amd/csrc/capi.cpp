@@ -1,0 +1,157 @@
+// extern "C" boundary of libsslcr.so: argument checks, error strings, no exceptions across the ABI.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "kernels.hpp"
+
+namespace sslcr {
+thread_local char g_err[512] = "";
+int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+int check(hipError_t e, const char* what) {
+  if (e == hipSuccess) return 0;
+  return fail("%s: %s", what, hipGetErrorString(e));
+}
+}  // namespace sslcr
+
+using namespace sslcr;
+
+#define NEED(cond, what) \
+  do {                   \
+    if (!(cond)) return fail("%s: invalid argument (%s)", __func__, what); \
+  } while (0)
+#define DT_OK(dt) NEED((dt) == SSLCR_F32 || (dt) == SSLCR_BF16, "dtype")
+
+extern "C" {
+
+int sslcr_version(void) { return 1; }
+const char* sslcr_last_error(void) { return g_err; }
+
+int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->x && d->w && d->y, "null tensor");
+  NEED(d->N > 0 && d->C > 0 && d->K > 0 && d->R > 0 && d->S > 0 && d->stride > 0, "shape");
+  NEED(d->C % (dtype == SSLCR_BF16 ? 64 : 32) == 0, "C must be a multiple of the 128-byte channel slab");
+  NEED(d->K % 64 == 0, "K % 64");
+  NEED(d->osh >= 1 && d->PH > 0 && d->PW > 0, "pixel space");
+  return check(launch_conv(dtype, *d, (hipStream_t)stream), "conv2d");
+}
+int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d) { return d ? conv_partials_rows(*d) : -1; }
+
+int sslcr_conv2d_wgrad(int dtype, const sslcr_wgrad_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->x && d->dy && d->dw, "null tensor");
+  NEED(d->C % 64 == 0 && d->K % 64 == 0, "C,K % 64");
+  NEED((d->R == 3 && d->S == 3) || (d->R == 1 && d->S == 1), "3x3 or 1x1");
+  return check(launch_wgrad(dtype, *d, (hipStream_t)stream), "conv2d_wgrad");
+}
+
+int sslcr_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, void* stream) {
+  NEED(in && byte_addr && out, "null");
+  return check(launch_probe_tr16(in, byte_addr, out, (hipStream_t)stream), "probe_tr16");
+}
+
+int sslcr_stem_conv(int dtype, const sslcr_stem_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->x && d->w && d->y, "null tensor");
+  NEED(d->OH == (d->H + 6 - 7) / 2 + 1 && d->OW == (d->W + 6 - 7) / 2 + 1, "7x7/2 pad 3 output dims");
+  return check(launch_stem(dtype, *d, (hipStream_t)stream), "stem_conv");
+}
+int sslcr_stem_partial_rows(const sslcr_stem_desc* d) { return d ? stem_partials_rows(*d) : -1; }
+int sslcr_stem_wgrad(int dtype, const sslcr_stem_wgrad_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->x && d->dy && d->dw, "null tensor");
+  return check(launch_stem_wgrad(dtype, *d, (hipStream_t)stream), "stem_wgrad");
+}
+
+int sslcr_bn_finalize(const sslcr_bn_finalize_desc* d, void* stream) {
+  NEED(d && d->C > 0, "desc");
+  NEED(d->sums_in || (d->partials && d->stage && d->rows > 0), "partials/stage");
+  NEED(d->sums_out || (d->gamma && d->beta && d->scale && d->shift && d->count > 0), "finalize outputs");
+  return check(launch_bn_finalize(*d, (hipStream_t)stream), "bn_finalize");
+}
+int sslcr_bn_act(int dtype, const sslcr_bn_act_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->x && d->y && d->scale && d->shift, "null");
+  NEED(d->C % 8 == 0, "C % 8");
+  return check(launch_bn_act(dtype, *d, (hipStream_t)stream), "bn_act");
+}
+int sslcr_bn_relu_maxpool(int dtype, const sslcr_pool_fwd_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->x && d->y, "null");
+  return check(launch_bn_relu_maxpool(dtype, *d, (hipStream_t)stream), "bn_relu_maxpool");
+}
+int sslcr_maxpool_relu_bwd(int dtype, const sslcr_pool_bwd_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->x && d->dy && d->dx && d->argmax, "null");
+  return check(launch_maxpool_relu_bwd(dtype, *d, (hipStream_t)stream), "maxpool_relu_bwd");
+}
+int sslcr_avgpool_fwd(int dtype, const void* x, float* y, int N, int HW, int C, void* stream) {
+  DT_OK(dtype);
+  NEED(x && y && N > 0 && HW > 0 && C % 8 == 0, "args");
+  return check(launch_avgpool_fwd(dtype, x, y, N, HW, C, (hipStream_t)stream), "avgpool_fwd");
+}
+int sslcr_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C, void* stream) {
+  DT_OK(dtype);
+  NEED(dy && dx && N > 0 && HW > 0 && C % 8 == 0, "args");
+  return check(launch_avgpool_bwd(dtype, dy, dx, N, HW, C, (hipStream_t)stream), "avgpool_bwd");
+}
+int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->dy && d->x && d->sums && d->mean, "null");
+  return check(launch_bn_bwd_reduce(dtype, *d, (hipStream_t)stream), "bn_bwd_reduce");
+}
+int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->dy && d->x && d->sums && d->dx && d->mean && d->invstd && d->scale, "null");
+  return check(launch_bn_bwd_apply(dtype, *d, (hipStream_t)stream), "bn_bwd_apply");
+}
+int sslcr_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, void* stream) {
+  NEED(sums && invstd && dgamma && dbeta, "null");
+  return check(launch_bn_param_grads(sums, invstd, dgamma, dbeta, C, (hipStream_t)stream), "bn_param_grads");
+}
+
+int sslcr_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu, void* stream) {
+  NEED(x && w && y && M > 0 && N > 0 && K > 0, "args");
+  return check(launch_linear_fwd(x, w, b, y, M, N, K, relu, (hipStream_t)stream), "linear_fwd");
+}
+int sslcr_linear_bwd(const float* x, const float* w, const float* dy, const float* yact, float* dx, float* dw, float* db,
+                     int M, int N, int K, int dx_accumulate, float* scratch, void* stream) {
+  NEED(x && w && dy && scratch && M > 0 && N > 0 && K > 0, "args");
+  return check(launch_linear_bwd(x, w, dy, yact, dx, dw, db, M, N, K, dx_accumulate, scratch, (hipStream_t)stream), "linear_bwd");
+}
+int sslcr_loss(const sslcr_loss_desc* d, void* stream) {
+  NEED(d && d->logits && d->out && d->nx > 0 && d->C > 0 && d->C <= 64, "args");
+  return check(launch_loss(*d, (hipStream_t)stream), "loss");
+}
+
+int sslcr_optimizer_step(const sslcr_tensor_desc* device_descs, int ntensors, int max_n, const sslcr_opt_desc* o, void* stream) {
+  NEED(device_descs && o && ntensors > 0 && max_n > 0, "args");
+  return check(launch_optimizer(device_descs, ntensors, max_n, *o, (hipStream_t)stream), "optimizer_step");
+}
+int sslcr_axpby(float* p, float* q, size_t n, float alpha, int copy_back, void* stream) {
+  NEED(p && q, "null");
+  return check(launch_axpby(p, q, n, alpha, copy_back, (hipStream_t)stream), "axpby");
+}
+int sslcr_fill(float* p, size_t n, float v, void* stream) {
+  NEED(p, "null");
+  return check(launch_fill(p, n, v, (hipStream_t)stream), "fill");
+}
+int sslcr_pack_conv(int dtype, const sslcr_pack_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->w && (d->w_fwd || d->w_dgrad), "null");
+  return check(launch_pack_conv(dtype, *d, (hipStream_t)stream), "pack_conv");
+}
+int sslcr_pack_stem(int dtype, const sslcr_pack_desc* d, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->w && d->w_fwd && d->K == 64 && d->C == 3 && d->R == 7 && d->S == 7, "stem shape");
+  return check(launch_pack_stem(dtype, *d, (hipStream_t)stream), "pack_stem");
+}
+
+}  // extern "C"

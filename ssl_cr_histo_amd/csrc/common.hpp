@@ -1,0 +1,85 @@
+// Common device/host helpers for the gfx950 (MI355X, CDNA4) engine.  HIP only -- no CUDA paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sslcr {
+
+typedef uint16_t bf16_t;                                    // raw bf16 bits
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+enum { DT_F32 = 0, DT_BF16 = 1 };
+
+// ---- bf16 <-> f32 (round to nearest even, NaN-preserving enough for activations)
+__device__ __forceinline__ float bf2f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- element traits: a 16-byte chunk holds EPC elements
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int EPC = 4;
+  static constexpr int DT = DT_F32;
+  __device__ static __forceinline__ void unpack(const u32x4_t& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+  }
+  __device__ static __forceinline__ u32x4_t pack(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = __float_as_uint(f[i]);
+    return v;
+  }
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int EPC = 8;
+  static constexpr int DT = DT_BF16;
+  __device__ static __forceinline__ void unpack(const u32x4_t& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = bf_lo(v[i]); f[2 * i + 1] = bf_hi(v[i]); }
+  }
+  __device__ static __forceinline__ u32x4_t pack(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+    return v;
+  }
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// ---- DPP all-reduce (sum) across the 16 lanes of a DPP row: quad xor1, quad xor2, half-mirror, mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+  return v;
+}
+// full 64-lane sum, result valid in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+__device__ __forceinline__ u32x4_t ld16(const void* p) { return *reinterpret_cast<const u32x4_t*>(p); }
+__device__ __forceinline__ void st16(void* p, const u32x4_t& v) { *reinterpret_cast<u32x4_t*>(p) = v; }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace sslcr

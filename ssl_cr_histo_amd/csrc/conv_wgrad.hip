@@ -1,0 +1,203 @@
+// Weight gradient of the NHWC convolutions on MFMA (autograd wgrad of the resnet18 BasicBlock convs).
+//
+//   dW[k][r][s][c] += sum_{n,ho,wo} dY[n,ho,wo,k] * act(X)[n, ho*stride-pad+r, wo*stride-pad+s, c]
+//
+// GEMM view per tap: D[kout][cin] = sum_pixels dY^T[kout][pixel] * X_tap[pixel][cin].  Both operands live in LDS
+// pixel-major ([pixel][64 channels], exactly as they sit in NHWC HBM) and the reduction dimension (pixels) is the
+// slow one, so bf16 fragments are fetched with the gfx950 transpose read ds_read_b64_tr_b16; fp32 uses scalar reads
+// into v_mfma_f32_16x16x4_f32.  One workgroup owns a 64(kout) x 64(cin) x all-taps tile for a slice of the pixels
+// and adds its fp32 result into dW with hardware float atomics (one slice per workgroup => few atomics per weight).
+// The producer's BatchNorm+ReLU is applied to X on the load path, like in the forward conv.
+#include "kernels.hpp"
+
+namespace sslcr {
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> struct WgFrag;
+template <> struct WgFrag<bf16_t> {
+  static constexpr int PS = 32;          // pixels per step = one 16x16x32 MFMA depth
+  // tile: [PS][128B]; (col0 = first of 16 channels) -> fragment of lane (li,g): pixels 8g..8g+7 of channel col0+li
+  __device__ static __forceinline__ bf16x8_t load(const char* tile, int col0, int li, int g) {
+    const char* p = tile + (8 * g + (li >> 2)) * 128 + (col0 + (li & 3) * 4) * 2;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 4 * 128));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+  }
+};
+
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int steps_per_split) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr bool BF = Elem<T>::DT == DT_BF16;
+  constexpr int PS = BF ? 32 : 16;             // pixels per step
+  constexpr int RB = 64 * sizeof(T);           // bytes per LDS row (64 channels)
+  constexpr int CPR = RB / 16;                 // 16-byte chunks per row
+  constexpr int TILE = PS * RB;                // 4 KiB
+  constexpr int BUF = (1 + TAPS) * TILE;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* s_scale = reinterpret_cast<float*>(smem + 2 * BUF);
+  float* s_shift = s_scale + 64;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int OHW = a.OH * a.OW;
+  const int M = a.N * OHW;
+  const int row = tid / CPR, chunk = tid % CPR;
+  const bool xform = a.in_scale != nullptr;
+  if (xform && tid < 64) { s_scale[tid] = a.in_scale[c0 + tid]; s_shift[tid] = a.in_shift[c0 + tid]; }
+
+  const int step0 = blockIdx.z * steps_per_split;
+  const int total_steps = (M + PS - 1) / PS;
+  int nsteps = total_steps - step0;
+  if (nsteps > steps_per_split) nsteps = steps_per_split;
+  if (nsteps <= 0) return;
+
+  const char* xg = reinterpret_cast<const char*>(a.x);
+  const char* dyg = reinterpret_cast<const char*>(a.dy);
+
+  u32x4_t yreg, xreg[TAPS];
+  unsigned inb = 0;
+  auto load_regs = [&](int s) {
+    const int m = (step0 + s) * PS + row;
+    inb = 0;
+    yreg = u32x4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) xreg[t] = u32x4_t{0u, 0u, 0u, 0u};
+    if (m < M) {
+      yreg = ld16(dyg + ((size_t)m * a.K + k0 + chunk * EPC) * sizeof(T));
+      const int n = m / OHW, rem = m - n * OHW;
+      const int ho = rem / a.OW, wo = rem - ho * a.OW;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int r = t / a.S, s_ = t - r * a.S;
+        const int h = ho * a.stride - a.pad + r, w = wo * a.stride - a.pad + s_;
+        if (h >= 0 && w >= 0 && h < a.H && w < a.W) {
+          xreg[t] = ld16(xg + ((size_t)((n * a.H + h) * a.W + w) * a.C + c0 + chunk * EPC) * sizeof(T));
+          inb |= 1u << t;
+        }
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+    char* b = smem + buf * BUF;
+    st16(b + row * RB + chunk * 16, yreg);
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      u32x4_t v = xreg[t];
+      if (xform && ((inb >> t) & 1u)) {
+        float f[EPC];
+        Elem<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float q = fmaf(f[e], s_scale[chunk * EPC + e], s_shift[chunk * EPC + e]);
+          f[e] = a.in_relu ? fmaxf(q, 0.f) : q;
+        }
+        v = Elem<T>::pack(f);
+      }
+      st16(b + (1 + t) * TILE + row * RB + chunk * 16, v);
+    }
+  };
+
+  f32x4_t acc[TAPS][4];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if (xform) __syncthreads();
+  load_regs(0);
+  store_lds(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const bool more = s + 1 < nsteps;
+    if (more) load_regs(s + 1);
+    const char* b = smem + (s & 1) * BUF;
+    if constexpr (BF) {
+      const bf16x8_t af = WgFrag<bf16_t>::load(b, 16 * wave, li, g);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const bf16x8_t bfrag = WgFrag<bf16_t>::load(b + (1 + t) * TILE, 16 * c, li, g);
+          acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag, acc[t][c], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int q = 0; q < PS / 4; ++q) {
+        const int prow = 4 * q + g;
+        const float av = *reinterpret_cast<const float*>(b + prow * RB + (16 * wave + li) * 4);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float bv = *reinterpret_cast<const float*>(b + (1 + t) * TILE + prow * RB + (16 * c + li) * 4);
+            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t][c], 0, 0, 0);
+          }
+      }
+    }
+    if (more) store_lds((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // D[row = kout 4g+j][col = cin li]  ->  dW[k][tap][c]
+  const int RS = a.R * a.S;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 16 * wave + 4 * g + j;
+        atomicAdd(a.dw + ((size_t)k * RS + t) * a.C + c0 + 16 * c + li, acc[t][c][j]);
+      }
+}
+
+template <typename T, int TAPS>
+static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
+  constexpr int PS = Elem<T>::DT == DT_BF16 ? 32 : 16;
+  const int M = a.N * a.OH * a.OW;
+  const int total_steps = cdiv(M, PS);
+  const int tiles = (a.K / 64) * (a.C / 64);
+  int splits = cdiv(1024, tiles);
+  const int max_splits = cdiv(total_steps, 8);      // at least 8 steps per workgroup
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int sps = cdiv(total_steps, splits);
+  splits = cdiv(total_steps, sps);
+  const size_t lds = 2 * (1 + TAPS) * 4096 + 2 * 64 * sizeof(float);
+  auto kern = wgrad_kernel<T, TAPS>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.K / 64, a.C / 64, splits), dim3(256), lds, st, a, sps);
+  return hipGetLastError();
+}
+
+// diagnostics: raw semantics of ds_read_b64_tr_b16 -- lane l reads at byte_addr[l] of a 2 KiB LDS image
+__global__ void probe_tr16_kernel(const uint16_t* in, const int* byte_addr, uint16_t* out) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[1024];
+  for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = in[i];
+  __syncthreads();
+  const char* p = reinterpret_cast<const char*>(lds) + byte_addr[threadIdx.x];
+  s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = (uint16_t)v[j];
+}
+hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, hipStream_t st) {
+  hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, st, in, byte_addr, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st) {
+  const bool three = a.R == 3;
+  if (dtype == DT_BF16) return three ? launch_w<bf16_t, 9>(a, st) : launch_w<bf16_t, 1>(a, st);
+  return three ? launch_w<float, 9>(a, st) : launch_w<float, 1>(a, st);
+}
+
+}  // namespace sslcr

@@ -1,0 +1,180 @@
+// fc / classifier heads (exact fp32 on v_mfma_f32_16x16x4_f32) and the fused loss forward+backward.
+// Replaces nn.Linear/ReLU of models/net.py:12-15,35-36,111 (K10/K11) and F.mse_loss / F.cross_entropy /
+// softmax+max pseudo-labels of eval_BreastPathQ_SSL_CR.py:92-95, eval_Camelyon_SSL_CR.py:110-116 (K12).
+#include "kernels.hpp"
+
+namespace sslcr {
+
+// C[M][N] (+)= A(M x K) * B(K x N); element (i,k) of A at A[i*sa_i + k*sa_k], (k,j) of B at B[k*sb_k + j*sb_j].
+// One wave per 16x16 tile; lane (li, g) feeds k = kb + 4g + e for MFMA e (any k-permutation is a valid sum order).
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, long sa_i, long sa_k,
+                                                       const float* __restrict__ B, long sb_k, long sb_j,
+                                                       float* __restrict__ C, int M, int N, int K,
+                                                       const float* __restrict__ bias, int relu, int accumulate) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int tiles_n = (N + 15) / 16;
+  const int tile = blockIdx.x * 4 + wave;
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  if (tm * 16 >= M) return;
+  const int i = tm * 16 + li, j = tn * 16 + li;
+  const bool iv = i < M, jv = j < N;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < K; kb += 16) {
+    float a[4], b[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = kb + 4 * g + e;
+      const bool kv = k < K;
+      a[e] = (iv && kv) ? A[(long)i * sa_i + (long)k * sa_k] : 0.f;
+      b[e] = (jv && kv) ? B[(long)k * sb_k + (long)j * sb_j] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+  }
+  // D[row = 4g + r][col = li]
+  if (jv) {
+    const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * 16 + 4 * g + r;
+      if (row < M) {
+        float v = acc[r] + bj;
+        float* c = C + (long)row * N + j;
+        if (accumulate) v += *c;
+        if (relu) v = fmaxf(v, 0.f);
+        *c = v;
+      }
+    }
+  }
+}
+
+static hipError_t gemm(const float* A, long sa_i, long sa_k, const float* B, long sb_k, long sb_j, float* C, int M, int N, int K,
+                       const float* bias, int relu, int accumulate, hipStream_t st) {
+  const int tiles = cdiv(M, 16) * cdiv(N, 16);
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, st, A, sa_i, sa_k, B, sb_k, sb_j, C, M, N, K, bias, relu, accumulate);
+  return hipGetLastError();
+}
+
+hipError_t launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu, hipStream_t st) {
+  // y = x[M][K] * w[N][K]^T  ->  B(k,j) = w[j*K + k]
+  return gemm(x, K, 1, w, 1, K, y, M, N, K, b, relu, 0, st);
+}
+
+__global__ __launch_bounds__(256) void relu_mask_colsum_kernel(const float* dy, const float* yact, float* dym, float* db, int M, int N) {
+  // one thread per column n: masks dy by (yact>0) into dym and accumulates the column sum into db
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) {
+    float v = dy[(long)m * N + n];
+    if (yact && !(yact[(long)m * N + n] > 0.f)) v = 0.f;
+    if (dym) dym[(long)m * N + n] = v;
+    s += v;
+  }
+  if (db) db[n] += s;
+}
+
+hipError_t launch_linear_bwd(const float* x, const float* w, const float* dy, const float* yact, float* dx, float* dw, float* db,
+                             int M, int N, int K, int dx_accumulate, float* scratch, hipStream_t st) {
+  const float* g = dy;
+  if (yact || db) {
+    hipLaunchKernelGGL(relu_mask_colsum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, dy, yact, yact ? scratch : nullptr, db, M, N);
+    if (yact) g = scratch;
+  }
+  hipError_t e = hipSuccess;
+  if (dx) {   // dx[M][K] = g[M][N] * w[N][K]
+    e = gemm(g, N, 1, w, K, 1, dx, M, K, N, nullptr, 0, dx_accumulate, st);
+    if (e != hipSuccess) return e;
+  }
+  if (dw) {   // dw[N][K] += g^T[N][M] * x[M][K]
+    e = gemm(g, 1, N, x, K, 1, dw, N, K, M, nullptr, 0, 1, st);
+  }
+  return e;
+}
+
+// ------------------------------------------------------------------ losses (single block; a few thousand rows at most)
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__device__ __forceinline__ int row_argmax(const float* l, int C) {
+  int b = 0;
+  float m = l[0];
+  for (int c = 1; c < C; ++c)
+    if (l[c] > m) { m = l[c]; b = c; }
+  return b;
+}
+
+// returns -log softmax(l)[y]; writes (softmax - onehot)*w into dl when dl != null
+__device__ __forceinline__ float ce_row(const float* l, int C, int y, float* dl, float w) {
+  float m = l[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, l[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += expf(l[c] - m);
+  const float lse = m + logf(s);
+  if (dl)
+    for (int c = 0; c < C; ++c) dl[c] = (expf(l[c] - lse) - (c == y ? 1.f : 0.f)) * w;
+  return lse - l[y];
+}
+
+__global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
+  __shared__ float sm[4];
+  const int C = a.C;
+  const bool ce = (a.kind == 1 || a.kind == 2);
+  float lx = 0.f, lu = 0.f, correct = 0.f;
+  for (int i = threadIdx.x; i < a.nx; i += 256) {
+    const float* l = a.logits + (long)i * C;
+    float* dl = a.dlogits ? a.dlogits + (long)i * C : nullptr;
+    if (ce) {
+      const int y = (int)a.target_i[i];
+      lx += ce_row(l, C, y, dl, a.inv_nx_global);
+      correct += (row_argmax(l, C) == y) ? 1.f : 0.f;
+    } else {                                   // mse: target is [nx] broadcast against [nx][1] (C == 1 in the reference)
+      for (int c = 0; c < C; ++c) {
+        const float d = l[c] - a.target_f[i];
+        lx += d * d;
+        if (dl) dl[c] = 2.f * d * a.inv_nx_global / (float)C;
+      }
+    }
+  }
+  if (a.kind == 0 || a.kind == 1) {
+    for (int i = threadIdx.x; i < a.nu; i += 256) {
+      const float* l = a.logits + (long)(a.nx + i) * C;
+      const float* t = a.logits_t + (long)i * C;
+      float* dl = a.dlogits ? a.dlogits + (long)(a.nx + i) * C : nullptr;
+      if (a.kind == 1) {
+        lu += ce_row(l, C, row_argmax(t, C), dl, a.lambda_u * a.inv_nu_global);    // hard pseudo label, no threshold
+      } else {
+        for (int c = 0; c < C; ++c) {
+          const float d = l[c] - t[c];          // F.mse_loss(logits_u_w, logits_u_s): teacher side carries no grad
+          lu += d * d;
+          if (dl) dl[c] = a.lambda_u * 2.f * d * a.inv_nu_global / (float)C;
+        }
+      }
+    }
+  }
+  const float sx = block_sum(lx, sm);
+  const float su = block_sum(lu, sm);
+  const float sc = block_sum(correct, sm);
+  if (threadIdx.x == 0) {
+    const float fx = ce ? a.inv_nx_global : a.inv_nx_global / (float)C;
+    const float fu = (a.kind == 1) ? a.inv_nu_global : a.inv_nu_global / (float)C;
+    const float loss_x = sx * fx, loss_u = su * fu;
+    a.out[0] = loss_x + a.lambda_u * loss_u;
+    a.out[1] = loss_x;
+    a.out[2] = loss_u;
+    a.out[3] = sc;
+  }
+}
+
+hipError_t launch_loss(const LossArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace sslcr

@@ -1,0 +1,56 @@
+// Internal kernel launch interface of the engine (host side).  The argument structs ARE the C-ABI
+// descriptors of include/sslcr.h.  Every launcher is asynchronous on `st`; no allocation, no sync.
+#pragma once
+#include "common.hpp"
+#include "../../include/sslcr.h"
+
+namespace sslcr {
+
+using ConvArgs = sslcr_conv_desc;
+using WgradArgs = sslcr_wgrad_desc;
+using StemArgs = sslcr_stem_desc;
+using StemWgradArgs = sslcr_stem_wgrad_desc;
+using BnFinalizeArgs = sslcr_bn_finalize_desc;
+using BnActArgs = sslcr_bn_act_desc;
+using PoolFwdArgs = sslcr_pool_fwd_desc;
+using PoolBwdArgs = sslcr_pool_bwd_desc;
+using BnBwdArgs = sslcr_bn_bwd_desc;
+using LossArgs = sslcr_loss_desc;
+using TensorDesc = sslcr_tensor_desc;
+using OptArgs = sslcr_opt_desc;
+using PackArgs = sslcr_pack_desc;
+
+// conv_igemm.hip
+hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st);
+int conv_tile_bp(const ConvArgs& a);
+int conv_partials_rows(const ConvArgs& a);
+// conv_wgrad.hip
+hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
+hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, hipStream_t st);
+// stem.hip
+hipError_t launch_stem(int dtype, const StemArgs& a, hipStream_t st);
+int stem_partials_rows(const StemArgs& a);
+hipError_t launch_stem_wgrad(int dtype, const StemWgradArgs& a, hipStream_t st);
+// bn_eltwise.hip
+hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st);
+hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st);
+hipError_t launch_bn_relu_maxpool(int dtype, const PoolFwdArgs& a, hipStream_t st);
+hipError_t launch_maxpool_relu_bwd(int dtype, const PoolBwdArgs& a, hipStream_t st);
+hipError_t launch_avgpool_fwd(int dtype, const void* x, float* y, int N, int HW, int C, hipStream_t st);
+hipError_t launch_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C, hipStream_t st);
+hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st);
+hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st);
+hipError_t launch_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, hipStream_t st);
+// heads.hip
+hipError_t launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu, hipStream_t st);
+hipError_t launch_linear_bwd(const float* x, const float* w, const float* dy, const float* yact, float* dx, float* dw, float* db,
+                             int M, int N, int K, int dx_accumulate, float* scratch, hipStream_t st);
+hipError_t launch_loss(const LossArgs& a, hipStream_t st);
+// optim.hip
+hipError_t launch_optimizer(const TensorDesc* d_descs, int ntensors, int max_n, const OptArgs& o, hipStream_t st);
+hipError_t launch_axpby(float* p, float* q, size_t n, float alpha, int copy_back, hipStream_t st);
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t st);
+hipError_t launch_pack_conv(int dtype, const PackArgs& a, hipStream_t st);
+hipError_t launch_pack_stem(int dtype, const PackArgs& a, hipStream_t st);
+
+}  // namespace sslcr

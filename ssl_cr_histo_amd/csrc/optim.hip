@@ -1,0 +1,134 @@
+// Fused multi-tensor optimizers, Lookahead/EMA axpby and weight packing (incl. eval-mode BN folding).
+// Replaces torch.optim.Adam / SGD(nesterov) per-tensor kernel storms, Lookahead (lookahead.py:81-106),
+// teacher refresh (K15) and prepares the KRSC / CRSK shadow weights the conv kernels consume.
+#include "kernels.hpp"
+
+namespace sslcr {
+
+__global__ __launch_bounds__(256) void optimizer_kernel(const TensorDesc* __restrict__ descs, const OptArgs o) {
+  const TensorDesc d = descs[blockIdx.y];
+  const int stride = gridDim.x * 256;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < d.n; i += stride) {
+    int gi = i;
+    if (d.K > 0) {                      // param [K][C][RS]  <-  grad [K][RS][C]
+      const int crs = d.C * d.RS;
+      const int k = i / crs, rem = i - k * crs;
+      const int c = rem / d.RS, rs = rem - c * d.RS;
+      gi = (k * d.RS + rs) * d.C + c;
+    }
+    float p = d.p[i];
+    const float g = fmaf(o.wd, p, d.g[gi] * o.grad_scale);
+    if (o.kind == 0) {                  // Adam, L2 decay in the gradient, eps outside the sqrt
+      float m = d.s1[i], v = d.s2[i];
+      m = fmaf(o.beta1, m, (1.f - o.beta1) * g);
+      v = fmaf(o.beta2, v, (1.f - o.beta2) * g * g);
+      d.s1[i] = m;
+      d.s2[i] = v;
+      const float denom = sqrtf(v) / sqrtf(o.bc2) + o.eps;
+      p -= (o.lr / o.bc1) * (m / denom);
+    } else {                            // SGD momentum, nesterov
+      float buf = o.first_step ? g : fmaf(o.momentum, d.s1[i], g);
+      d.s1[i] = buf;
+      p -= o.lr * fmaf(o.momentum, buf, g);
+    }
+    d.p[i] = p;
+  }
+}
+
+hipError_t launch_optimizer(const TensorDesc* d_descs, int ntensors, int max_n, const OptArgs& o, hipStream_t st) {
+  int bx = cdiv(max_n, 256 * 8);
+  if (bx > 64) bx = 64;
+  hipLaunchKernelGGL(optimizer_kernel, dim3(bx, ntensors), dim3(256), 0, st, d_descs, o);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(float* p, float* q, size_t n, float alpha, int copy_back) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = alpha * p[i] + (1.f - alpha) * q[i];
+    p[i] = v;
+    if (copy_back) q[i] = v;
+  }
+}
+hipError_t launch_axpby(float* p, float* q, size_t n, float alpha, int copy_back, hipStream_t st) {
+  size_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(axpby_kernel, dim3((int)b), dim3(256), 0, st, p, q, n, alpha, copy_back);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, size_t n, float v) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = v;
+}
+hipError_t launch_fill(float* p, size_t n, float v, hipStream_t st) {
+  size_t b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(fill_kernel, dim3((int)b), dim3(256), 0, st, p, n, v);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ __launch_bounds__(256) void pack_conv_kernel(const PackArgs a) {
+  const int RS = a.R * a.S;
+  const int total = a.K * a.C * RS;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    // i enumerates the fwd layout [K][RS][C]
+    const int k = i / (RS * a.C), rem = i - k * RS * a.C;
+    const int rs = rem / a.C, c = rem - rs * a.C;
+    const float w = a.w[((size_t)k * a.C + c) * RS + rs];
+    if (a.w_fwd) {
+      float f = 1.f;
+      if (a.gamma) f = a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
+      Elem<T>::st(reinterpret_cast<T*>(a.w_fwd) + i, w * f);
+    }
+    if (a.w_dgrad) Elem<T>::st(reinterpret_cast<T*>(a.w_dgrad) + ((size_t)c * RS + rs) * a.K + k, w);
+  }
+  if (a.gamma && a.bias_out) {
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < a.K; k += gridDim.x * 256) {
+      const float f = a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
+      a.bias_out[k] = a.beta[k] - a.rmean[k] * f;
+    }
+  }
+}
+hipError_t launch_pack_conv(int dtype, const PackArgs& a, hipStream_t st) {
+  int b = cdiv(a.K * a.C * a.R * a.S, 256);
+  if (b > 2048) b = 2048;
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(b), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(b), dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+// stem: [64][3][7][7] -> [64][7][8][4] (s = 7 and c = 3 are zero padding of the MFMA K dimension)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_stem_kernel(const PackArgs a) {
+  const int total = 64 * 7 * 8 * 4;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) % 7, k = i / 224;
+    float w = 0.f;
+    if (c < 3 && s < 7) {
+      w = a.w[((k * 3 + c) * 7 + r) * 7 + s];
+      if (a.gamma) w *= a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
+    }
+    Elem<T>::st(reinterpret_cast<T*>(a.w_fwd) + i, w);
+  }
+  if (a.gamma && a.bias_out && blockIdx.x == 0 && threadIdx.x < 64) {
+    const int k = threadIdx.x;
+    const float f = a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
+    a.bias_out[k] = a.beta[k] - a.rmean[k] * f;
+  }
+}
+hipError_t launch_pack_stem(int dtype, const PackArgs& a, hipStream_t st) {
+  if (dtype == DT_BF16) {
+    hipLaunchKernelGGL(pack_stem_kernel<bf16_t>, dim3(56), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(pack_stem_kernel<float>, dim3(56), dim3(256), 0, st, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace sslcr

@@ -1,0 +1,284 @@
+// ResNet18 stem on MFMA: uint8/fp32 NCHW ingestion fused with conv1 (7x7 stride 2 pad 3, 3->64), and its wgrad.
+// Replaces `.float()` + `reshape` + resnet18.conv1 (eval_BreastPathQ_SSL_CR.py:68-74, models/net.py:32,77).
+//
+// The 0..255 input values are exact in bf16, so the cast is free.  A workgroup stages a (2*8+5) x (2*16+6) x 4-channel
+// halo of the planar NCHW image in LDS (4th channel = 0) and produces an 8x16 tile of output pixels x 64 kouts.
+// The GEMM K dimension is ordered (r, s8, c4): for each filter row r, 8 taps x 4 channels = 32 = one bf16 MFMA depth,
+// and a lane's 8 K-elements are two horizontally adjacent halo pixels = 16 contiguous LDS bytes (tap s=7 and c=3
+// carry zero weights: 147 useful of 224 MACs).  Workgroups are persistent over tiles: the 28 KiB packed weight block
+// is staged once, and BatchNorm (sum, sumsq) partials are accumulated in registers across tiles.
+#include "kernels.hpp"
+
+namespace sslcr {
+
+constexpr int TH = 8, TW = 16;                 // output tile
+constexpr int HR = 2 * TH + 5;                 // 21 halo rows
+constexpr int HC = 2 * TW + 6;                 // 38 halo cols (even, covers the zero-weight tap s=7)
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+static int stem_grid(int N, int OH, int OW) {
+  const int tiles = N * cdiv(OH, TH) * cdiv(OW, TW);
+  return tiles < 1024 ? tiles : 1024;
+}
+int stem_partials_rows(const StemArgs& a) { return stem_grid(a.N, a.OH, a.OW) * 4; }
+
+template <typename T, bool INF32>
+__device__ __forceinline__ void stem_load_halo(T* halo, const void* xv, int n, int H, int W, int hi0, int wi0) {
+  for (int idx = threadIdx.x; idx < 3 * HR * HC; idx += 256) {
+    const int c = idx / (HR * HC), rem = idx - c * (HR * HC);
+    const int rr = rem / HC, cc = rem - rr * HC;
+    const int h = hi0 + rr, w = wi0 + cc;
+    float v = 0.f;
+    if (h >= 0 && w >= 0 && h < H && w < W) {
+      const size_t o = ((size_t)(n * 3 + c) * H + h) * W + w;
+      v = INF32 ? reinterpret_cast<const float*>(xv)[o] : (float)reinterpret_cast<const uint8_t*>(xv)[o];
+    }
+    Elem<T>::st(halo + (rr * HC + cc) * 4 + c, v);
+  }
+}
+
+template <typename T, bool INF32>
+__global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int tiles_h, int tiles_w, int ntiles) {
+  constexpr bool BF = Elem<T>::DT == DT_BF16;
+  constexpr int WROW = 224 * sizeof(T) + 16;     // padded weight row: odd number of 16-byte slots
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* w_lds = smem;
+  T* halo = reinterpret_cast<T*>(smem + 64 * WROW);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  // stage the packed weights [64][224] once
+  {
+    const char* wg = reinterpret_cast<const char*>(a.w);
+    constexpr int CH = 224 * sizeof(T) / 16;     // 16-byte chunks per row
+    for (int i = tid; i < 64 * CH; i += 256) {
+      const int k = i / CH, c = i - k * CH;
+      st16(w_lds + k * WROW + c * 16, ld16(wg + (size_t)i * 16));
+    }
+    for (int i = tid; i < HR * HC * 4; i += 256) Elem<T>::st(halo + i, 0.f);
+  }
+  float s1[16], s2[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+  float bias[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bias[j] = a.bias ? a.bias[g * 16 + j] : 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
+    const int th = rem / tiles_w, tw = rem - th * tiles_w;
+    const int ho0 = th * TH, wo0 = tw * TW;
+    __syncthreads();
+    stem_load_halo<T, INF32>(halo, a.x, n, a.H, a.W, 2 * ho0 - 3, 2 * wo0 - 3);
+    __syncthreads();
+
+    f32x4_t acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) acc[t][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+      if constexpr (BF) {
+        u32x4_t af[4], bfr[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int k = (li >> 2) * 16 + t * 4 + (li & 3);
+          af[t] = ld16(w_lds + k * WROW + (r * 8 + 2 * g) * 4 * sizeof(T));
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int hr = 2 * (2 * wave + p) + r;
+          bfr[p] = ld16(reinterpret_cast<const char*>(halo) + ((hr * HC + 2 * li + 2 * g) * 4) * sizeof(T));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int p = 0; p < 2; ++p)
+            acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[t]), __builtin_bit_cast(bf16x8_t, bfr[p]), acc[t][p], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+          float av[4], bv[2];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int k = (li >> 2) * 16 + t * 4 + (li & 3);
+            av[t] = *reinterpret_cast<const float*>(w_lds + k * WROW + ((r * 8 + s) * 4 + g) * 4);
+          }
+#pragma unroll
+          for (int p = 0; p < 2; ++p) {
+            const int hr = 2 * (2 * wave + p) + r;
+            bv[p] = reinterpret_cast<const float*>(halo)[(hr * HC + 2 * li + s) * 4 + g];
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) acc[t][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t], bv[p], acc[t][p], 0, 0, 0);
+        }
+      }
+    }
+    // epilogue: lane holds kouts g*16 .. g*16+15 of pixel (ho0+2*wave+p, wo0+li)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int ho = ho0 + 2 * wave + p, wo = wo0 + li;
+      const bool valid = ho < a.OH && wo < a.OW;
+      float v[16];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float q = valid ? acc[t][p][j] : 0.f;
+          s1[t * 4 + j] += q;
+          s2[t * 4 + j] = fmaf(q, q, s2[t * 4 + j]);
+          float o = q + bias[t * 4 + j];
+          v[t * 4 + j] = a.relu ? fmaxf(o, 0.f) : o;
+        }
+      if (valid) {
+        char* yp = reinterpret_cast<char*>(a.y) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64 + g * 16) * sizeof(T);
+        constexpr int EPC = Elem<T>::EPC;
+#pragma unroll
+        for (int q = 0; q < 16 / EPC; ++q) st16(yp + q * 16, Elem<T>::pack(v + q * EPC));
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { s1[j] = row16_sum(s1[j]); s2[j] = row16_sum(s2[j]); }
+    if (li == 0) {
+      float* sp = a.stats + ((size_t)(blockIdx.x * 4 + wave) * 2) * 64 + g * 16;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { sp[j] = s1[j]; sp[64 + j] = s2[j]; }
+    }
+  }
+}
+
+template <typename T, bool INF32>
+static hipError_t launch_stem_t(const StemArgs& a, hipStream_t st) {
+  const int th = cdiv(a.OH, TH), tw = cdiv(a.OW, TW);
+  const int ntiles = a.N * th * tw;
+  const size_t lds = 64 * (224 * sizeof(T) + 16) + HR * HC * 4 * sizeof(T);
+  auto kern = stem_fwd_kernel<T, INF32>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(stem_grid(a.N, a.OH, a.OW)), dim3(256), lds, st, a, th, tw, ntiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_stem(int dtype, const StemArgs& a, hipStream_t st) {
+  if (dtype == DT_BF16) return a.in_f32 ? launch_stem_t<bf16_t, true>(a, st) : launch_stem_t<bf16_t, false>(a, st);
+  return a.in_f32 ? launch_stem_t<float, true>(a, st) : launch_stem_t<float, false>(a, st);
+}
+
+// ------------------------------------------------------------------ stem wgrad
+// D[kout][feature (r,s8,c4)] = sum_pixels dY^T[kout][pixel] * patch[pixel][feature]; the patch operand is read straight
+// out of the halo with per-lane addresses (ds_read_b64_tr_b16 delivers the pixel-major -> K-major transpose for free).
+template <typename T, bool INF32>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, int tiles_h, int tiles_w, int ntiles) {
+  constexpr bool BF = Elem<T>::DT == DT_BF16;
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int PS = BF ? 32 : 16;               // pixels per step
+  constexpr int RB = 64 * sizeof(T);
+  constexpr int CPR = RB / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ytile = smem;                            // [PS][RB] = 4 KiB
+  T* halo = reinterpret_cast<T*>(smem + PS * RB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int row = tid / CPR, chunk = tid % CPR;
+  for (int i = tid; i < HR * HC * 4; i += 256) Elem<T>::st(halo + i, 0.f);
+
+  f32x4_t acc[14];
+#pragma unroll
+  for (int f = 0; f < 14; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
+    const int th = rem / tiles_w, tw = rem - th * tiles_w;
+    const int ho0 = th * TH, wo0 = tw * TW;
+    __syncthreads();
+    stem_load_halo<T, INF32>(halo, a.x, n, a.H, a.W, 2 * ho0 - 3, 2 * wo0 - 3);
+    for (int step = 0; step < TH * TW / PS; ++step) {
+      // pixel p of the step -> (hl, wl) inside the tile
+      {
+        const int p = step * PS + row;
+        const int ho = ho0 + p / TW, wo = wo0 + p % TW;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (ho < a.OH && wo < a.OW)
+          v = ld16(reinterpret_cast<const char*>(a.dy) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64 + chunk * EPC) * sizeof(T));
+        __syncthreads();                         // previous step's reads of ytile are done
+        st16(ytile + row * RB + chunk * 16, v);
+      }
+      __syncthreads();
+      if constexpr (BF) {
+        // A: dY^T, kouts 16*wave + li, pixels 8g..8g+7
+        const char* pa = ytile + (8 * g + (li >> 2)) * RB + (16 * wave + (li & 3) * 4) * 2;
+        s16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(pa));
+        s16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(pa + 4 * RB));
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
+        // this lane's source pixels for the transpose read: j = li>>2 (+4), feature quad q = li&3
+        const int p0 = step * PS + 8 * g + (li >> 2), p1 = p0 + 4;
+        const int h0 = 2 * (p0 / TW), w0 = 2 * (p0 % TW), h1 = 2 * (p1 / TW), w1 = 2 * (p1 % TW);
+#pragma unroll
+        for (int f = 0; f < 14; ++f) {
+          const int r = f >> 1, s0 = (f & 1) * 4;
+          const char* b0 = reinterpret_cast<const char*>(halo) + (((h0 + r) * HC + w0 + s0 + (li & 3)) * 4) * 2;
+          const char* b1 = reinterpret_cast<const char*>(halo) + (((h1 + r) * HC + w1 + s0 + (li & 3)) * 4) * 2;
+          s16x4_t blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(b0));
+          s16x4_t bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(b1));
+          const bf16x8_t bfrag = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7));
+          acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag, acc[f], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < PS / 4; ++q) {
+          const int pl = 4 * q + g;
+          const float av = *reinterpret_cast<const float*>(ytile + pl * RB + (16 * wave + li) * 4);
+          const int p = step * PS + pl;
+          const int hh = 2 * (p / TW), ww = 2 * (p % TW);
+#pragma unroll
+          for (int f = 0; f < 14; ++f) {
+            const int r = f >> 1, s = (f & 1) * 4 + (li >> 2), c = li & 3;
+            const float bv = reinterpret_cast<const float*>(halo)[((hh + r) * HC + ww + s) * 4 + c];
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[f], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // D[row = kout 16*wave+4g+j][col = feature li -> (s = s0 + li>>2, c = li&3)] -> dW[k][c][r][s]
+#pragma unroll
+  for (int f = 0; f < 14; ++f) {
+    const int r = f >> 1, s = (f & 1) * 4 + (li >> 2), c = li & 3;
+    if (s < 7 && c < 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 16 * wave + 4 * g + j;
+        atomicAdd(a.dw + ((k * 3 + c) * 7 + r) * 7 + s, acc[f][j]);
+      }
+    }
+  }
+}
+
+template <typename T, bool INF32>
+static hipError_t launch_stem_wgrad_t(const StemWgradArgs& a, hipStream_t st) {
+  constexpr int PS = Elem<T>::DT == DT_BF16 ? 32 : 16;
+  const int th = cdiv(a.OH, TH), tw = cdiv(a.OW, TW);
+  const int ntiles = a.N * th * tw;
+  const size_t lds = PS * 64 * sizeof(T) + HR * HC * 4 * sizeof(T);
+  int grid = ntiles < 512 ? ntiles : 512;
+  hipLaunchKernelGGL((stem_wgrad_kernel<T, INF32>), dim3(grid), dim3(256), lds, st, a, th, tw, ntiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_stem_wgrad(int dtype, const StemWgradArgs& a, hipStream_t st) {
+  if (dtype == DT_BF16) return a.in_f32 ? launch_stem_wgrad_t<bf16_t, true>(a, st) : launch_stem_wgrad_t<bf16_t, false>(a, st);
+  return a.in_f32 ? launch_stem_wgrad_t<float, true>(a, st) : launch_stem_wgrad_t<float, false>(a, st);
+}
+
+}  // namespace sslcr

@@ -1,0 +1,240 @@
+"""Thin torch-tensor front end of the per-kernel C-ABI entry points (include/sslcr.h).
+
+Tensors are only device memory here: every function fills a descriptor with raw pointers/sizes and calls
+libsslcr.so on the current HIP stream.  Activations NHWC, weights KRSC; ``dtype`` 0 = fp32, 1 = bf16.
+"""
+import torch
+
+from . import _lib as L
+
+F32, BF16 = 0, 1
+
+
+def tdtype(dtype):
+    return torch.bfloat16 if dtype == BF16 else torch.float32
+
+
+def _dt(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None:
+            if not t.is_cuda:
+                raise L.SslcrError("sslcr kernels need device tensors (no CPU fallback)")
+            if not t.is_contiguous():
+                raise L.SslcrError("sslcr kernels need contiguous tensors")
+
+
+def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bias=None, residual=None, relu=False,
+           want_stats=False, out=None, transposed=False, out_hw=None, osh=1, accumulate=False, pixel_hw=None):
+    """x NHWC [N,H,W,C], w KRSC [K,R,S,C] -> y NHWC (+ partial stats [rows,2,K] fp32).
+
+    transposed=True is the dgrad gather: pixel space = the conv's input (pixel_hw), x = dY, w = [C][R][S][K]."""
+    _chk(x, w, in_scale, in_shift, bias, residual, out)
+    dt = _dt(x)
+    N, H, W, C = x.shape
+    K, R, S, C2 = w.shape
+    assert C2 == C and w.dtype == x.dtype
+    if transposed:
+        PH, PW = pixel_hw
+    else:
+        PH, PW = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+    OH, OW = out_hw if out_hw is not None else (PH * osh, PW * osh)
+    y = out if out is not None else torch.empty((N, OH, OW, K), dtype=x.dtype, device=x.device)
+    d = L.ConvDesc(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(in_scale), L.ptr(in_shift), L.ptr(bias), L.ptr(residual), None,
+                   N, H, W, C, K, R, S, stride, pad, PH, PW, OH, OW, osh, int(transposed), int(in_relu), int(relu),
+                   int(accumulate))
+    stats = None
+    if want_stats:
+        rows = L.lib().sslcr_conv2d_partial_rows(d)
+        stats = torch.empty((rows, 2, K), dtype=torch.float32, device=x.device)
+        d.stats = L.ptr(stats)
+    L.check(L.lib().sslcr_conv2d(dt, d, L.stream_ptr()))
+    return (y, stats) if want_stats else y
+
+
+def conv2d_wgrad(x, dy, dw, R, S, stride, pad, *, in_scale=None, in_shift=None, in_relu=False):
+    """accumulate dW [K,R,S,C] fp32 += wgrad(x NHWC, dy NHWC)."""
+    _chk(x, dy, dw, in_scale, in_shift)
+    N, H, W, C = x.shape
+    _, OH, OW, K = dy.shape
+    assert dw.shape == (K, R, S, C) and dw.dtype == torch.float32
+    d = L.WgradDesc(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
+                    N, H, W, C, K, R, S, stride, pad, OH, OW)
+    L.check(L.lib().sslcr_conv2d_wgrad(_dt(x), d, L.stream_ptr()))
+
+
+def pack_conv(w_kcrs, dtype, *, fwd=True, dgrad=False, bn=None, eps=1e-5):
+    """PyTorch [K,C,R,S] fp32 -> (w_fwd [K,R,S,C], w_dgrad [C,R,S,K], bias[K]|None) in engine dtype.
+    bn = (gamma, beta, running_mean, running_var) folds eval-mode BatchNorm into w_fwd/bias."""
+    _chk(w_kcrs)
+    K, C, R, S = w_kcrs.shape
+    dev = w_kcrs.device
+    wf = torch.empty((K, R, S, C), dtype=tdtype(dtype), device=dev) if fwd else None
+    wd = torch.empty((C, R, S, K), dtype=tdtype(dtype), device=dev) if dgrad else None
+    bias = torch.empty(K, dtype=torch.float32, device=dev) if bn is not None else None
+    g, b, rm, rv = bn if bn is not None else (None, None, None, None)
+    d = L.PackDesc(L.ptr(w_kcrs), L.ptr(wf), L.ptr(wd), L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), eps, L.ptr(bias),
+                   K, C, R, S)
+    L.check(L.lib().sslcr_pack_conv(dtype, d, L.stream_ptr()))
+    return wf, wd, bias
+
+
+def pack_stem(w_kcrs, dtype, *, bn=None, eps=1e-5):
+    _chk(w_kcrs)
+    dev = w_kcrs.device
+    wf = torch.empty((64, 7, 8, 4), dtype=tdtype(dtype), device=dev)
+    bias = torch.empty(64, dtype=torch.float32, device=dev) if bn is not None else None
+    g, b, rm, rv = bn if bn is not None else (None, None, None, None)
+    d = L.PackDesc(L.ptr(w_kcrs), L.ptr(wf), None, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), eps, L.ptr(bias), 64, 3, 7, 7)
+    L.check(L.lib().sslcr_pack_stem(dtype, d, L.stream_ptr()))
+    return wf, bias
+
+
+def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False):
+    """x NCHW uint8|fp32 [N,3,H,W] -> NHWC [N,OH,OW,64] in w_packed's dtype (+ partial stats)."""
+    _chk(x_nchw, w_packed, bias)
+    N, _, H, W = x_nchw.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert x_nchw.dtype in (torch.uint8, torch.float32)
+    y = torch.empty((N, OH, OW, 64), dtype=w_packed.dtype, device=x_nchw.device)
+    d = L.StemDesc(L.ptr(x_nchw), L.ptr(w_packed), L.ptr(y), L.ptr(bias), None, N, H, W, OH, OW,
+                   int(x_nchw.dtype == torch.float32), int(relu))
+    stats = None
+    if want_stats:
+        rows = L.lib().sslcr_stem_partial_rows(d)
+        stats = torch.empty((rows, 2, 64), dtype=torch.float32, device=x_nchw.device)
+        d.stats = L.ptr(stats)
+    L.check(L.lib().sslcr_stem_conv(_dt(w_packed), d, L.stream_ptr()))
+    return (y, stats) if want_stats else y
+
+
+def stem_wgrad(x_nchw, dy, dw):
+    _chk(x_nchw, dy, dw)
+    N, _, H, W = x_nchw.shape
+    _, OH, OW, _ = dy.shape
+    d = L.StemWgradDesc(L.ptr(x_nchw), L.ptr(dy), L.ptr(dw), N, H, W, OH, OW, int(x_nchw.dtype == torch.float32))
+    L.check(L.lib().sslcr_stem_wgrad(_dt(dy), d, L.stream_ptr()))
+
+
+def bn_finalize(partials, count, gamma, beta, *, running_mean=None, running_var=None, nbt=None, momentum=0.1,
+                eps=1e-5, replay=1):
+    """partial rows [rows,2,C] -> (scale, shift, mean, invstd); running stats updated in place `replay` times."""
+    _chk(partials, gamma, beta, running_mean, running_var, nbt)
+    rows, _, Cn = partials.shape
+    dev = partials.device
+    scale, shift, mean, invstd = (torch.empty(Cn, dtype=torch.float32, device=dev) for _ in range(4))
+    stage = torch.empty((32, 2, Cn), dtype=torch.float64, device=dev)
+    d = L.BnFinalizeDesc(L.ptr(partials), rows, Cn, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift),
+                         L.ptr(mean), L.ptr(invstd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), momentum, eps,
+                         replay, None, None, L.ptr(stage))
+    L.check(L.lib().sslcr_bn_finalize(d, L.stream_ptr()))
+    return scale, shift, mean, invstd
+
+
+def bn_act(x, scale, shift, *, res=None, rscale=None, rshift=None, relu=True):
+    _chk(x, scale, shift, res, rscale, rshift)
+    y = torch.empty_like(x)
+    Cn = x.shape[-1]
+    d = L.BnActDesc(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(res), L.ptr(rscale), L.ptr(rshift), L.ptr(y),
+                    x.numel() // Cn, Cn, int(relu))
+    L.check(L.lib().sslcr_bn_act(_dt(x), d, L.stream_ptr()))
+    return y
+
+
+def bn_relu_maxpool(x, scale, shift):
+    _chk(x, scale, shift)
+    N, H, W, Cn = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, OH, OW, Cn), dtype=x.dtype, device=x.device)
+    am = torch.empty((N, OH, OW, Cn), dtype=torch.uint8, device=x.device)
+    d = L.PoolFwdDesc(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(y), L.ptr(am), N, H, W, Cn, OH, OW)
+    L.check(L.lib().sslcr_bn_relu_maxpool(_dt(x), d, L.stream_ptr()))
+    return y, am
+
+
+def maxpool_relu_bwd(dy, argmax, x, scale, shift):
+    _chk(dy, argmax, x, scale, shift)
+    N, H, W, Cn = x.shape
+    _, OH, OW, _ = dy.shape
+    dx = torch.empty_like(x)
+    d = L.PoolBwdDesc(L.ptr(dy), L.ptr(argmax), L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(dx), N, H, W, Cn, OH, OW)
+    L.check(L.lib().sslcr_maxpool_relu_bwd(_dt(x), d, L.stream_ptr()))
+    return dx
+
+
+def avgpool_fwd(x):
+    _chk(x)
+    N, H, W, Cn = x.shape
+    y = torch.empty((N, Cn), dtype=torch.float32, device=x.device)
+    L.check(L.lib().sslcr_avgpool_fwd(_dt(x), L.ptr(x), L.ptr(y), N, H * W, Cn, L.stream_ptr()))
+    return y
+
+
+def avgpool_bwd(dy, shape, dtype):
+    _chk(dy)
+    N, H, W, Cn = shape
+    dx = torch.empty(shape, dtype=tdtype(dtype), device=dy.device)
+    L.check(L.lib().sslcr_avgpool_bwd(dtype, L.ptr(dy), L.ptr(dx), N, H * W, Cn, L.stream_ptr()))
+    return dx
+
+
+def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, want_g=False, count=None):
+    """-> (dx, sums[2,C] fp64, g|None)."""
+    _chk(dy, x, scale, shift, mean, invstd, yact)
+    Cn = x.shape[-1]
+    pixels = x.numel() // Cn
+    sums = torch.zeros((2, Cn), dtype=torch.float64, device=x.device)
+    dx = torch.empty_like(x)
+    g = torch.empty_like(x) if want_g else None
+    d = L.BnBwdDesc(L.ptr(dy), L.ptr(x), L.ptr(yact), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(sums),
+                    L.ptr(dx), L.ptr(g), pixels, Cn, int(relu_from_x), float(count if count is not None else pixels))
+    L.check(L.lib().sslcr_bn_bwd_reduce(_dt(x), d, L.stream_ptr()))
+    L.check(L.lib().sslcr_bn_bwd_apply(_dt(x), d, L.stream_ptr()))
+    return dx, sums, g
+
+
+def bn_param_grads(sums, invstd, dgamma, dbeta):
+    _chk(sums, invstd, dgamma, dbeta)
+    L.check(L.lib().sslcr_bn_param_grads(L.ptr(sums), L.ptr(invstd), L.ptr(dgamma), L.ptr(dbeta), invstd.numel(),
+                                         L.stream_ptr()))
+
+
+def linear_fwd(x, w, b, relu=False):
+    _chk(x, w, b)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    L.check(L.lib().sslcr_linear_fwd(L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), M, N, K, int(relu), L.stream_ptr()))
+    return y
+
+
+def linear_bwd(x, w, dy, *, yact=None, dw=None, db=None, want_dx=True, dx=None, dx_accumulate=False):
+    _chk(x, w, dy, yact, dw, db, dx)
+    M, K = x.shape
+    N = w.shape[0]
+    if want_dx and dx is None:
+        dx = torch.empty((M, K), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    L.check(L.lib().sslcr_linear_bwd(L.ptr(x), L.ptr(w), L.ptr(dy), L.ptr(yact), L.ptr(dx) if want_dx else None,
+                                     L.ptr(dw), L.ptr(db), M, N, K, int(dx_accumulate), L.ptr(scratch), L.stream_ptr()))
+    return dx
+
+
+def loss(kind, logits, *, logits_t=None, target_f=None, target_i=None, nx, lambda_u=1.0, want_grad=True,
+         nx_global=None, nu_global=None):
+    _chk(logits, logits_t, target_f, target_i)
+    Ns, Cn = logits.shape
+    nu = Ns - nx
+    dl = torch.zeros_like(logits) if want_grad else None
+    out = torch.zeros(4, dtype=torch.float32, device=logits.device)
+    d = L.LossDesc(kind, L.ptr(logits), L.ptr(logits_t), L.ptr(target_f), L.ptr(target_i), L.ptr(dl), L.ptr(out), nx, nu,
+                   Cn, lambda_u, 1.0 / (nx_global or nx), 1.0 / max(1, (nu_global or nu)))
+    L.check(L.lib().sslcr_loss(d, L.stream_ptr()))
+    return out, dl

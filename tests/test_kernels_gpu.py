@@ -1,0 +1,352 @@
+"""Per-kernel parity: every HIP kernel (through the C-ABI) against the CPU oracle (oracle/kernels_ref.py,
+torch CPU fp32) on seeded inputs.  fp32 mode must hold 1e-4 (exact-fp32 MFMA, summation order only);
+bf16 mode is checked against the oracle fed the SAME bf16-rounded inputs (tolerance = bf16 output rounding)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import kernels_ref as R  # noqa: E402
+
+
+def _k():
+    from ssl_cr_histo_amd import kernels as K
+    return K
+
+
+DEV = "cuda:0"
+TOL = {0: 2e-4, 1: 1.2e-2}
+
+
+def rnd(seed, shape, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * scale)
+
+
+def to_dev(t, dtype):
+    K = _k()
+    return t.to(DEV).to(K.tdtype(dtype)).contiguous()
+
+
+def q(t, dtype):
+    """round-trip through the engine storage dtype (so the oracle sees the same operand values)."""
+    return t.to(torch.bfloat16).float() if dtype == 1 else t.float()
+
+
+def close(got, want, tol, what=""):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item() + 1e-20
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e} > {tol})"
+
+
+def test_probe_tr16():
+    """ds_read_b64_tr_b16: out lane i elem j <- in lane (4j + i/4) elem (i%4), per 16-lane group."""
+    from ssl_cr_histo_amd import _lib as L
+    img = torch.arange(1024, dtype=torch.int16, device=DEV)
+    # canonical: group g reads the [4][16] block at rows 4g..4g+3 of a [16][64]-element image; lane i' -> row i'>>2, cols 4*(i'&3)
+    lane = torch.arange(64)
+    g, i = lane // 16, lane % 16
+    addr = (((4 * g + (i >> 2)) * 64 + (i & 3) * 4) * 2).to(torch.int32).to(DEV)
+    out = torch.zeros((64, 4), dtype=torch.int16, device=DEV)
+    L.check(L.lib().sslcr_probe_tr16(L.ptr(img), L.ptr(addr), L.ptr(out), L.stream_ptr()))
+    torch.cuda.synchronize()
+    want = torch.zeros((64, 4), dtype=torch.int16)
+    for l in range(64):
+        for j in range(4):
+            want[l, j] = (4 * (l // 16) + j) * 64 + (l % 16)      # row j of the group's block, column i
+    assert torch.equal(out.cpu(), want), out.cpu()[:20]
+
+
+CONV_CASES = [
+    # N, H, W, C, K, R, stride, pad
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (3, 9, 11, 64, 128, 3, 2, 1),      # ragged M, stride 2
+    (2, 8, 8, 128, 256, 1, 2, 0),      # 1x1 downsample
+    (1, 8, 8, 256, 256, 3, 1, 1),
+    (40, 32, 32, 64, 64, 3, 1, 1),     # M = 40960 < 65536 -> 64-pixel tiles ; many tiles
+    (72, 32, 32, 64, 128, 3, 1, 1),    # M = 73728 -> 128-pixel tiles, K=128 config
+    (70, 32, 32, 64, 64, 3, 1, 1),     # 128x64 config
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_raw_stats(case, dtype):
+    K = _k()
+    N, H, W, C, Ko, Rr, stride, pad = case
+    x = q(rnd(1, (N, H, W, C)), dtype)
+    w = q(rnd(2, (Ko, Rr, Rr, C), 0.05), dtype)
+    y, stats = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), stride, pad, want_stats=True)
+    want = R.conv_fwd(x, w, stride, pad)
+    close(y, want, TOL[dtype], "conv raw")
+    s, ss = R.channel_stats(want)
+    st = stats.double().sum(0).cpu()
+    close(st[0], s, 2e-4 if dtype == 0 else 2e-3, "sum")
+    close(st[1], ss, 2e-4 if dtype == 0 else 2e-3, "sumsq")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_conv_fwd_fused_prologue_epilogue(dtype):
+    K = _k()
+    N, H, W, C, Ko = 2, 12, 12, 128, 128
+    x = q(rnd(3, (N, H, W, C)), dtype)
+    w = q(rnd(4, (Ko, 3, 3, C), 0.05), dtype)
+    sc, sh = rnd(5, (C,)).abs() + 0.5, rnd(6, (C,))
+    bias = rnd(7, (Ko,))
+    res = q(rnd(8, (N, H, W, Ko)), dtype)
+    y = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, in_scale=sc.to(DEV), in_shift=sh.to(DEV), in_relu=True,
+                 bias=bias.to(DEV), residual=to_dev(res, dtype), relu=True)
+    # the engine rounds the transformed operand to the storage dtype before the MFMA
+    xt = q(F.relu(x * sc + sh), dtype)
+    want = R.conv_fwd(xt, w, 1, 1, bias=bias, residual=res, relu=True)
+    close(y, want, TOL[dtype], "fused conv")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 9, 11, 64, 128, 3, 2, 1), (2, 8, 8, 128, 256, 1, 2, 0),
+                                  (2, 10, 10, 256, 256, 3, 1, 1)])
+def test_conv_dgrad(case, dtype):
+    K = _k()
+    N, H, W, C, Ko, Rr, stride, pad = case
+    OH, OW = (H + 2 * pad - Rr) // stride + 1, (W + 2 * pad - Rr) // stride + 1
+    dy = q(rnd(11, (N, OH, OW, Ko)), dtype)
+    w = q(rnd(12, (Ko, Rr, Rr, C), 0.05), dtype)
+    wd = w.permute(3, 1, 2, 0).contiguous()               # [C][R][S][K]
+    want = R.conv_dgrad(dy, w, stride, pad, (H, W))
+    if Rr == 1:
+        # 1x1/2 downsample dgrad: scatter-accumulate into an existing gradient (identity-path add)
+        base = q(rnd(13, (N, H, W, C)), dtype)
+        out = to_dev(base, dtype)
+        K.conv2d(to_dev(dy, dtype), to_dev(wd, dtype), 1, 0, out=out, out_hw=(H, W), osh=2, accumulate=True)
+        close(out, want + base, TOL[dtype], "dgrad 1x1 scatter")
+    else:
+        res = q(rnd(14, (N, H, W, C)), dtype)
+        dx = K.conv2d(to_dev(dy, dtype), to_dev(wd, dtype), stride, pad, transposed=True, pixel_hw=(H, W),
+                      residual=to_dev(res, dtype))
+        close(dx, want + res, TOL[dtype], "dgrad")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 9, 11, 64, 128, 3, 2, 1), (2, 8, 8, 128, 256, 1, 2, 0),
+                                  (5, 12, 12, 128, 64, 3, 1, 1)])
+def test_conv_wgrad(case, dtype):
+    K = _k()
+    N, H, W, C, Ko, Rr, stride, pad = case
+    OH, OW = (H + 2 * pad - Rr) // stride + 1, (W + 2 * pad - Rr) // stride + 1
+    x = q(rnd(21, (N, H, W, C)), dtype)
+    dy = q(rnd(22, (N, OH, OW, Ko)), dtype)
+    sc, sh = rnd(23, (C,)).abs() + 0.5, rnd(24, (C,))
+    dw = torch.zeros((Ko, Rr, Rr, C), dtype=torch.float32, device=DEV)
+    K.conv2d_wgrad(to_dev(x, dtype), to_dev(dy, dtype), dw, Rr, Rr, stride, pad, in_scale=sc.to(DEV), in_shift=sh.to(DEV),
+                   in_relu=True)
+    xt = q(F.relu(x * sc + sh), dtype)
+    want = R.conv_wgrad(xt, dy, (Ko, Rr, Rr, C), stride, pad)
+    close(dw, want, 2e-4 if dtype == 0 else 3e-3, "wgrad")
+    # accumulate semantics: a second call doubles it
+    K.conv2d_wgrad(to_dev(x, dtype), to_dev(dy, dtype), dw, Rr, Rr, stride, pad, in_scale=sc.to(DEV), in_shift=sh.to(DEV),
+                   in_relu=True)
+    close(dw, 2 * want, 2e-4 if dtype == 0 else 3e-3, "wgrad x2")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("in_u8", [True, False])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (3, 56, 40), (1, 256, 256)])
+def test_stem(shape, in_u8, dtype):
+    K = _k()
+    N, H, W = shape
+    xu = torch.from_numpy(np.random.RandomState(31).randint(0, 256, (N, 3, H, W), dtype=np.uint8))
+    w = rnd(32, (64, 3, 7, 7), 0.03)
+    xin = xu if in_u8 else xu.float()
+    wp, _ = K.pack_stem(w.to(DEV), dtype)
+    y, stats = K.stem_conv(xin.to(DEV), wp, want_stats=True)
+    want = R.nhwc(F.conv2d(xu.float(), q(w, dtype), None, 2, 3))
+    close(y, want, TOL[dtype], "stem conv")
+    s, ss = R.channel_stats(want)
+    st = stats.double().sum(0).cpu()
+    close(st[0], s, 2e-4 if dtype == 0 else 3e-3, "stem sum")
+    close(st[1], ss, 2e-4 if dtype == 0 else 3e-3, "stem sumsq")
+    # folded-BN eval form: bias + relu
+    g, b, rm, rv = rnd(33, (64,)).abs() + 0.5, rnd(34, (64,)), rnd(35, (64,)), rnd(36, (64,)).abs() + 0.5
+    wp2, bias = K.pack_stem(w.to(DEV), dtype, bn=tuple(t.to(DEV) for t in (g, b, rm, rv)))
+    y2 = K.stem_conv(xin.to(DEV), wp2, bias=bias, relu=True)
+    f = g / torch.sqrt(rv + 1e-5)
+    want2 = F.relu(R.nhwc(F.conv2d(xu.float(), q(w * f.view(-1, 1, 1, 1), dtype), None, 2, 3)) + (b - rm * f))
+    close(y2, want2, TOL[dtype], "stem folded")
+    # wgrad
+    OH, OW = want.shape[1:3]
+    dy = q(rnd(37, (N, OH, OW, 64)), dtype)
+    dw = torch.zeros((64, 3, 7, 7), dtype=torch.float32, device=DEV)
+    K.stem_wgrad(xin.to(DEV), to_dev(dy, dtype), dw)
+    wantw = torch.nn.grad.conv2d_weight(xu.float(), (64, 3, 7, 7), R.nchw(dy), 2, 3)
+    close(dw, wantw, 2e-4 if dtype == 0 else 3e-3, "stem wgrad")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_bn_forward_chain(dtype):
+    """conv stats -> finalize (x3 replay) -> bn_act / pool, against F.batch_norm train mode."""
+    K = _k()
+    N, H, W, C = 4, 16, 16, 64
+    x = q(rnd(41, (N, H, W, C), 3.0) + 1.5, dtype)
+    w = q(rnd(42, (C, 3, 3, C), 0.05), dtype)
+    gamma, beta = rnd(43, (C,)).abs() + 0.5, rnd(44, (C,))
+    rm, rv = rnd(45, (C,)), rnd(46, (C,)).abs() + 0.5
+    raw, stats = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, want_stats=True)
+    rm_d, rv_d = rm.to(DEV).clone(), rv.to(DEV).clone()
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    sc, sh, mean, invstd = K.bn_finalize(stats, N * H * W, gamma.to(DEV), beta.to(DEV), running_mean=rm_d, running_var=rv_d,
+                                         nbt=nbt, replay=3)
+    raw_ref = R.conv_fwd(x, w, 1, 1)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    for _ in range(3):
+        bn_ref = F.batch_norm(R.nchw(raw_ref), rm_r, rv_r, gamma, beta, True, 0.1, 1e-5)
+    t = 3e-4 if dtype == 0 else 5e-3
+    close(rm_d, rm_r, t, "running_mean x3")
+    close(rv_d, rv_r, t, "running_var x3")
+    assert int(nbt.item()) == 3
+    res = q(rnd(47, (N, H, W, C)), dtype)
+    y = K.bn_act(raw, sc, sh, res=to_dev(res, dtype), relu=True)
+    close(y, F.relu(R.nhwc(bn_ref) + res), 3e-4 if dtype == 0 else 1.5e-2, "bn+res+relu")
+    rsc, rsh = rnd(48, (C,)).abs() + 0.5, rnd(49, (C,))
+    y2 = K.bn_act(raw, sc, sh, res=to_dev(res, dtype), rscale=rsc.to(DEV), rshift=rsh.to(DEV), relu=True)
+    close(y2, F.relu(R.nhwc(bn_ref) + res * rsc + rsh), 3e-4 if dtype == 0 else 1.5e-2, "bn+bn(res)+relu")
+    # maxpool of relu(bn) and its backward
+    pooled, am = K.bn_relu_maxpool(raw, sc, sh)
+    act = F.relu(bn_ref).detach().requires_grad_(True)
+    pool_ref = F.max_pool2d(act, 3, 2, 1)
+    close(pooled, R.nhwc(pool_ref), 3e-4 if dtype == 0 else 1.5e-2, "maxpool")
+    ap = K.avgpool_fwd(pooled)
+    close(ap, pooled.float().mean((1, 2)), 1e-5, "avgpool")
+    if dtype == 0:
+        dyp = rnd(50, tuple(pool_ref.shape))
+        pool_ref.backward(dyp)
+        gact = act.grad * (act > 0)
+        dx = K.maxpool_relu_bwd(to_dev(R.nhwc(dyp), dtype), am, raw, sc, sh)
+        close(dx, R.nhwc(gact), 3e-4, "maxpool+relu bwd")
+    dap = K.avgpool_bwd(ap, tuple(pooled.shape), dtype)
+    close(dap, (ap / (pooled.shape[1] * pooled.shape[2]))[:, None, None, :].expand(pooled.shape), 1e-2 if dtype else 1e-6, "avgpool bwd")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("mode", ["yact", "from_x", "none"])
+def test_bn_backward(mode, dtype):
+    K = _k()
+    N, H, W, C = 3, 10, 10, 128
+    x = q(rnd(51, (N, H, W, C), 2.0) + 0.7, dtype)
+    dy = q(rnd(52, (N, H, W, C)), dtype)
+    gamma, beta = rnd(53, (C,)).abs() + 0.5, rnd(54, (C,))
+    xr = R.nchw(x).clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    bn = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    out = F.relu(bn) if mode != "none" else bn
+    out.backward(R.nchw(dy))
+    xf = x.reshape(-1, C).double()
+    mean = xf.mean(0)
+    var = xf.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = (gamma.double() * invstd).float()
+    shift = (beta.double() - mean * gamma.double() * invstd).float()
+    yact = to_dev(q(R.nhwc(out.detach()), dtype), dtype) if mode == "yact" else None
+    dx, sums, g = K.bn_bwd(to_dev(dy, dtype), to_dev(x, dtype), scale.to(DEV), shift.to(DEV), mean.float().to(DEV),
+                           invstd.float().to(DEV), yact=yact, relu_from_x=(mode == "from_x"), want_g=True)
+    t = 5e-4 if dtype == 0 else 2e-2
+    close(dx, R.nhwc(xr.grad), t, "bn dx")
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    K.bn_param_grads(sums, invstd.float().to(DEV), dg, db)
+    close(dg, gr.grad, t, "dgamma")
+    close(db, br.grad, t, "dbeta")
+    mask = (out.detach() > 0).float() if mode != "none" else torch.ones_like(out)
+    close(g, dy * R.nhwc(mask), 1e-6, "g")
+
+
+def test_linear_and_loss():
+    K = _k()
+    M, Kd, Nn = 37, 1024, 512
+    x, w, b = rnd(61, (M, Kd)), rnd(62, (Nn, Kd), 0.03), rnd(63, (Nn,))
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.relu(F.linear(xr, wr, br))
+    y = K.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+    close(y, yr, 2e-5, "linear fwd")
+    dy = rnd(64, (M, Nn))
+    yr.backward(dy)
+    dw = torch.zeros((Nn, Kd), device=DEV)
+    db = torch.zeros(Nn, device=DEV)
+    dx = K.linear_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), yact=y, dw=dw, db=db)
+    close(dx, xr.grad, 5e-5, "linear dx")
+    close(dw, wr.grad, 5e-5, "linear dw")
+    close(db, br.grad, 5e-5, "linear db")
+    # losses
+    for kind, Cn in ((0, 1), (1, 2), (1, 9), (2, 6), (3, 1)):
+        nx, nu = 6, 14 if kind in (0, 1) else 0
+        lg = rnd(65 + Cn, (nx + nu, Cn), 2.0).requires_grad_(True)
+        lt = rnd(66 + Cn, (max(nu, 1), Cn), 2.0)
+        lam = 0.7
+        if kind in (0, 3):
+            tgt = rnd(67, (nx,)).abs()
+            lx = F.mse_loss(lg[:nx], tgt.view(-1, 1).expand(nx, Cn))
+            lu = F.mse_loss(lt, lg[nx:]) if kind == 0 else torch.zeros(())
+            out, dl = K.loss(kind, lg.detach().to(DEV), logits_t=lt.to(DEV) if kind == 0 else None, target_f=tgt.to(DEV), nx=nx, lambda_u=lam)
+            correct = None
+        else:
+            tgt = torch.from_numpy(np.random.RandomState(68).randint(0, Cn, (nx,)).astype(np.int64))
+            lx = F.cross_entropy(lg[:nx], tgt)
+            lu = F.cross_entropy(lg[nx:], torch.softmax(lt, -1).max(-1)[1]) if kind == 1 else torch.zeros(())
+            out, dl = K.loss(kind, lg.detach().to(DEV), logits_t=lt.to(DEV) if kind == 1 else None, target_i=tgt.to(DEV), nx=nx, lambda_u=lam)
+            correct = (lg[:nx].argmax(1) == tgt).sum().item()
+        total = lx + lam * lu
+        total.backward()
+        o = out.cpu()
+        assert abs(o[0] - total.item()) < 1e-5 * max(1, abs(total.item())), (kind, o, total)
+        assert abs(o[1] - lx.item()) < 1e-5 * max(1, abs(lx.item()))
+        assert abs(o[2] - float(lu)) < 1e-5 * max(1, abs(float(lu)))
+        if correct is not None:
+            assert int(o[3]) == correct
+        close(dl, lg.grad, 1e-5, f"dlogits kind {kind}")
+
+
+@pytest.mark.parametrize("kind", ["adam", "sgd"])
+def test_optimizer_and_pack(kind):
+    from ssl_cr_histo_amd import _lib as L
+    K = _k()
+    shapes = [(64, 3, 7, 7), (128, 64, 3, 3), (128,), (10, 768), (256, 128, 1, 1)]
+    ps = [rnd(70 + i, s, 0.1) for i, s in enumerate(shapes)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    opt = (torch.optim.Adam(ref, lr=1e-2, betas=(0.9, 0.999), weight_decay=1e-4) if kind == "adam"
+           else torch.optim.SGD(ref, lr=1e-2, momentum=0.9, weight_decay=1e-4, nesterov=True))
+    dev_p = [p.to(DEV).contiguous() for p in ps]
+    s1 = [torch.zeros_like(p) for p in dev_p]
+    s2 = [torch.zeros_like(p) for p in dev_p]
+    for step in range(1, 4):
+        grads = [rnd(100 * step + i, s) for i, s in enumerate(shapes)]
+        dev_g = []
+        descs = (L.TensorDesc * len(shapes))()
+        for i, (p, g) in enumerate(zip(dev_p, grads)):
+            if g.dim() == 4 and i != 0:                       # engine grad layout KRSC; stem keeps PyTorch layout
+                gd = g.permute(0, 2, 3, 1).contiguous().to(DEV)
+                Kk, Cc, RS = g.shape[0], g.shape[1], g.shape[2] * g.shape[3]
+            else:
+                gd = g.to(DEV)
+                Kk, Cc, RS = 0, 0, 0
+            dev_g.append(gd)
+            descs[i] = L.TensorDesc(L.ptr(p), L.ptr(gd), L.ptr(s1[i]), L.ptr(s2[i]), p.numel(), Kk, Cc, RS)
+        dd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(DEV)
+        o = L.OptDesc(0 if kind == "adam" else 1, 1e-2, 0.9, 0.999, 1e-8, 1e-4, 0.9, 1 - 0.9 ** step, 1 - 0.999 ** step,
+                      int(step == 1), 1.0)
+        L.check(L.lib().sslcr_optimizer_step(L.ptr(dd), len(shapes), max(p.numel() for p in dev_p), o, L.stream_ptr()))
+        for r, g in zip(ref, grads):
+            r.grad = g.clone()
+        opt.step()
+    for p, r in zip(dev_p, ref):
+        close(p, r, 2e-5, f"{kind} param")
+    # pack: layouts and folding
+    w = rnd(90, (128, 64, 3, 3), 0.05)
+    wf, wd, _ = K.pack_conv(w.to(DEV), 0, fwd=True, dgrad=True)
+    assert torch.equal(wf.cpu(), w.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(wd.cpu(), w.permute(1, 2, 3, 0).contiguous())
+    a, b2 = rnd(91, (64,)).to(DEV), rnd(92, (64,)).to(DEV)
+    ref_a = 0.3 * a + 0.7 * b2
+    L.check(L.lib().sslcr_axpby(L.ptr(a), L.ptr(b2), 64, 0.3, 1, L.stream_ptr()))
+    close(a, ref_a, 1e-6, "axpby")
+    assert torch.equal(a, b2)
