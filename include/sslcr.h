@@ -167,6 +167,85 @@ typedef struct sslcr_pack_desc {
 int sslcr_pack_conv(int dtype, const sslcr_pack_desc* d, void* stream);
 int sslcr_pack_stem(int dtype, const sslcr_pack_desc* d, void* stream);
 
+/* ==================================================================================================
+ * Engine: the whole ResNet18 TripletNet(_Finetune)+head graph, forward / backward / update, orchestrated
+ * natively (one C call per step).  Replaces the step bodies of the reference's train()/validate():
+ *   eval_BreastPathQ_SSL_CR.py:65-100, eval_Camelyon_SSL_CR.py:94-121, eval_Kather_SSL_CR.py:56-105,
+ *   pretrain_BreastPathQ.py:42-61 and :110-128, eval_Camelyon_SSL.py:52-98, eval_BreastPathQ_SSL.py:52-84.
+ * ================================================================================================== */
+typedef struct sslcr_ctx sslcr_ctx;
+typedef struct sslcr_net sslcr_net;
+
+int sslcr_create(sslcr_ctx** out, int device, int dtype);
+int sslcr_destroy(sslcr_ctx* ctx);
+/* one process per GPU: rank 0 makes the 128-byte id, the host broadcasts it (torch.distributed), every rank inits.
+ * With a communicator: gradients are all-reduced (bucketed, overlapped with backward) and train-mode BatchNorm uses
+ * GLOBAL batch statistics (all-reduce of per-channel sums), which is what makes N ranks equal the single-device
+ * reference (the reference's nn.DataParallel BN is per-replica, eval_BreastPathQ_SSL_CR.py:474-477). */
+int sslcr_comm_unique_id(void* id128);
+int sslcr_comm_init(sslcr_ctx* ctx, const void* id128, int rank, int world);
+
+typedef struct sslcr_net_desc {
+  float* const* params;                    /* [nparams] device pointers, named_parameters() order of models/net.py:
+                                              0..59 resnet18 backbone, 60..63 fc.0/fc.2, then the classifier (2 or 4) */
+  int nparams;
+  float* const* bn_running_mean;           /* [20] in graph order */
+  float* const* bn_running_var;
+  int64_t* const* bn_num_batches_tracked;
+  const uint8_t* requires_grad;            /* [nparams] host flags (freeze-by-index, eval_BreastPathQ_SSL_CR.py:408-441) */
+  int head_kind;                           /* 0 FinetuneResNet 768->C (models/net.py:107-115); 1 Classifier 768->128->C (:8-20) */
+  int num_classes;
+  int triplet;                             /* 0 TripletNet_Finetune (models/net.py:70-103); 1 TripletNet (:25-66) */
+} sslcr_net_desc;
+int sslcr_net_create(sslcr_ctx* ctx, const sslcr_net_desc* d, sslcr_net** out);
+int sslcr_net_destroy(sslcr_net* net);
+int sslcr_net_set_requires_grad(sslcr_net* net, const uint8_t* flags);
+/* re-derive the shadow weights from the bound fp32 parameters: mode bit0 = train packs (KRSC + dgrad CRSK),
+ * bit1 = eval packs (BatchNorm running stats folded into KRSC weights + bias). Call after any parameter change. */
+int sslcr_net_pack(sslcr_net* net, int mode, void* stream);
+
+/* forward.  x2/x3 only for triplet nets.  train=0: eval-mode BN (folded), nothing saved.  train=1: batch-stat BN,
+ * running stats updated (x3 for TripletNet_Finetune), activations kept for sslcr_net_backward. */
+int sslcr_net_forward(sslcr_net* net, int train, const void* x1, const void* x2, const void* x3, int in_f32,
+                      int N, int H, int W, float* feats, float* logits, void* stream);
+/* backward of the last train forward from d(loss)/d(logits); zeroes then fills the engine's gradient buffer;
+ * all-reduces it when a communicator is set. */
+int sslcr_net_backward(sslcr_net* net, const float* dlogits, void* stream);
+int sslcr_net_grad(sslcr_net* net, int param_index, float* out, void* stream);      /* -> PyTorch layout */
+/* fused multi-tensor update of every requires_grad parameter; state1/state2 = per-parameter optimizer state
+ * (exp_avg/exp_avg_sq or momentum_buffer) owned by the caller, NULL entries for frozen parameters */
+int sslcr_net_optimizer_step(sslcr_net* net, const sslcr_opt_desc* o, float* const* state1, float* const* state2, void* stream);
+int sslcr_net_lookahead(sslcr_net* net, float* const* cached, float alpha, void* stream);   /* lookahead.py:93-97 */
+int sslcr_net_ema_from(sslcr_net* teacher, sslcr_net* student, float decay, void* stream);  /* decay 0 == deepcopy (:515-516) */
+
+typedef struct sslcr_ssl_cr_desc {
+  int kind;                 /* 0 mse+mse (BreastPathQ) ; 1 ce + hard-pseudo-label ce (Camelyon, Kather) */
+  const void* x_student;    /* [nx+nu,3,H,W]: labeled then strong-augmented unlabeled (torch.cat at :82) */
+  const void* x_teacher;    /* [nu,3,H,W]: weak-augmented unlabeled */
+  int in_f32, nx, nu, H, W;
+  const float* target_f; const int64_t* target_i;
+  float lambda_u;
+  int nx_global, nu_global; /* global batch counts (== nx, nu on one GPU) */
+  float* feats;             /* [nx+nu,768] out */
+  float* logits;            /* [nx+nu,C] out */
+  float* logits_t;          /* [nu,C] out */
+  float* losses;            /* [4] out: loss, loss_x, loss_u, #correct */
+  int backward;
+} sslcr_ssl_cr_desc;
+int sslcr_step_ssl_cr(sslcr_net* teacher, sslcr_net* student, const sslcr_ssl_cr_desc* d, void* stream);
+
+typedef struct sslcr_sup_desc {
+  int kind;                 /* 2 cross-entropy ; 3 mse */
+  const void* x1; const void* x2; const void* x3;   /* x2,x3: TripletNet (RSP) only */
+  int in_f32, n, H, W;
+  const float* target_f; const int64_t* target_i;
+  int n_global;
+  float* feats; float* logits; float* losses;
+  int train;                /* 1: train-mode BN ; 0: validate() */
+  int backward;
+} sslcr_sup_desc;
+int sslcr_step_supervised(sslcr_net* net, const sslcr_sup_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

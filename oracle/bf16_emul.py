@@ -1,0 +1,68 @@
+"""bf16-storage emulation of the student backbone on CPU (test oracle).
+
+The engine's bf16 mode stores activations, conv weights and activation gradients in bf16 (fp32 accumulate, fp32
+BatchNorm statistics, fp32 heads/losses/optimizer).  On small, randomly initialised problems that rounding alone moves
+gradients by tens of percent relative to fp32 (BatchNorm backward subtracts large projections; ReLU / max-pool masks
+flip).  This module reproduces the SAME KIND of rounding with plain torch CPU ops -- round-to-bf16 in forward and in
+backward at every tensor the engine materialises -- so the tests can tell "bf16 noise of the expected size" from a
+kernel bug: the engine's error against the fp32 oracle must stay within a small factor of this emulation's error.
+It is a yardstick for tolerances only; parity is carried by the fp32 engine mode.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import model as M
+
+
+class _Round(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).float()
+
+
+rnd = _Round.apply
+
+
+def _bn(x, p, pre):
+    return F.batch_norm(x, None, None, p[pre + ".weight"], p[pre + ".bias"], True, 0.1, 1e-5)
+
+
+def backbone_train(p, x, q=rnd, pre="model."):
+    """train-mode resnet18 backbone with rounding `q` where the engine stores bf16 (q = identity gives fp32)."""
+    w = (lambda k: q(p[pre + k]))
+    x = q(F.conv2d(x, w("conv1.weight"), None, 2, 3))
+    x = q(F.max_pool2d(F.relu(_bn(x, p, pre + "bn1")), 3, 2, 1))
+    for name, cin, cout, stride, ds in M.BLOCKS:
+        n = pre + name
+        o = q(F.conv2d(x, w(name + ".conv1.weight"), None, stride, 1))
+        o = q(F.relu(_bn(o, p, n + ".bn1")))                 # rounded on the consumer's load path
+        o = q(F.conv2d(o, w(name + ".conv2.weight"), None, 1, 1))
+        o = _bn(o, p, n + ".bn2")
+        if ds:
+            i = q(F.conv2d(x, w(name + ".downsample.0.weight"), None, stride, 0))
+            i = _bn(i, p, n + ".downsample.1")
+        else:
+            i = x
+        x = q(F.relu(o + i))
+    return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+
+
+def ssl_cr_grads(kind, p, x, y, u_s, logits_t, lambda_u, emulate):
+    """gradients of the SSL_CR loss w.r.t. every entry of `p` (leaf tensors), bf16-emulated or plain fp32."""
+    for v in p.values():
+        v.grad = None
+    q = rnd if emulate else (lambda t: t)
+    e = backbone_train(p, torch.cat((x, u_s)), q)
+    f = M.fc_head(p, torch.cat((e, e), 1))
+    logits = M.classifier_forward(p, torch.cat((f, f, f), 1))
+    nx = x.shape[0]
+    if kind == "mse":
+        loss = F.mse_loss(logits[:nx], y.view(-1, 1)) + lambda_u * F.mse_loss(logits_t, logits[nx:])
+    else:
+        loss = F.cross_entropy(logits[:nx], y) + lambda_u * F.cross_entropy(logits[nx:], torch.softmax(logits_t, -1).max(-1)[1])
+    loss.backward()
+    return {k: v.grad.clone() for k, v in p.items()}, logits.detach(), float(loss.detach())

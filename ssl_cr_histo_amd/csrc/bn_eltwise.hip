@@ -397,15 +397,18 @@ hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-__global__ void bn_param_grads_kernel(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C) {
+__global__ void bn_param_grads_kernel(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, float scale) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  dgamma[c] += (float)(sums[C + c] * (double)invstd[c]);
-  dbeta[c] += (float)sums[c];
+  dgamma[c] += (float)(sums[C + c] * (double)invstd[c] * (double)scale);
+  dbeta[c] += (float)(sums[c] * (double)scale);
+}
+hipError_t launch_bn_param_grads_scaled(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, invstd, dgamma, dbeta, C, scale);
+  return hipGetLastError();
 }
 hipError_t launch_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, hipStream_t st) {
-  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, sums, invstd, dgamma, dbeta, C);
-  return hipGetLastError();
+  return launch_bn_param_grads_scaled(sums, invstd, dgamma, dbeta, C, 1.f, st);
 }
 
 }  // namespace sslcr

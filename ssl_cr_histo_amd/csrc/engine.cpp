@@ -1,0 +1,986 @@
+// Native orchestration of the ResNet18 TripletNet(_Finetune)+head graph: forward (eval-folded or train-mode BN),
+// backward, gradient all-reduce (RCCL, bucketed + overlapped), synced BatchNorm, fused optimizer.  One C call per
+// step; every kernel goes to the caller's stream.  See include/sslcr.h for the reference code each entry replaces.
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <vector>
+
+#include "kernels.hpp"
+
+using namespace sslcr;
+
+#define TRY(expr)                                   \
+  do {                                              \
+    hipError_t _e = (expr);                         \
+    if (_e != hipSuccess) return check(_e, #expr);  \
+  } while (0)
+#define TRYI(expr)            \
+  do {                        \
+    int _r = (expr);          \
+    if (_r != 0) return _r;   \
+  } while (0)
+#define TRYN(expr)                                                                     \
+  do {                                                                                 \
+    ncclResult_t _r = (expr);                                                          \
+    if (_r != ncclSuccess) return fail("%s: %s", #expr, ncclGetErrorString(_r));       \
+  } while (0)
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) {
+      hipError_t e = hipFree(p);          // synchronises the device: only ever happens while shapes grow
+      if (e != hipSuccess) return check(e, "hipFree");
+      p = nullptr;
+      cap = 0;
+    }
+    bytes = (bytes + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return check(e, "hipMalloc");
+    cap = bytes;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct Carver {                 // bump allocator over a DevBuf region (offsets only; ensure() afterwards)
+  size_t off = 0;
+  size_t take(size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  }
+};
+
+struct ConvL {
+  int cin = 0, cout = 0, k = 0, stride = 1, pad = 0, pidx = -1;
+  void *w_fwd = nullptr, *w_dg = nullptr, *w_fold = nullptr;
+  float* b_fold = nullptr;
+};
+struct BnL {
+  int C = 0, pg = -1, pb = -1, bidx = -1;
+};
+struct BlockL {
+  ConvL c1, c2, ds;
+  BnL b1, b2, bd;
+  bool has_ds = false;
+  int pstart = 0;
+};
+struct BnSaved {
+  float *scale, *shift, *mean, *invstd;
+};
+struct PassState {
+  const void* x = nullptr;
+  int in_f32 = 0, N = 0, H = 0, W = 0;
+  DevBuf mem;
+  char* raw0 = nullptr;
+  char* pooled = nullptr;
+  uint8_t* argmax = nullptr;
+  struct {
+    char *raw1, *raw2, *rawd, *y;
+  } blk[8];
+  BnSaved bn[20];
+  float* E = nullptr;
+};
+
+}  // namespace
+
+struct sslcr_ctx {
+  int device = 0, dtype = 0;
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_ready[8], ev_done = nullptr;
+  DevBuf scratch;     // eval-forward activations and backward transients (never live at the same time)
+  DevBuf partials;    // BN partial rows
+  DevBuf small;       // bn stage/sums, unit scale/shift
+  double* bn_stage = nullptr;
+  double* bn_sums = nullptr;
+  float *ones = nullptr, *zeros = nullptr;
+  size_t esz() const { return dtype == DT_BF16 ? 2 : 4; }
+};
+
+struct sslcr_net {
+  sslcr_ctx* ctx = nullptr;
+  int nparams = 0, head_kind = 0, ncls = 1, triplet = 0;
+  std::vector<float*> params;
+  std::vector<uint8_t> rg;
+  std::vector<int> psize;
+  std::vector<size_t> goff;
+  float* bn_rm[20];
+  float* bn_rv[20];
+  int64_t* bn_nbt[20];
+  ConvL stem;
+  BnL bn0;
+  BlockL blocks[8];
+  DevBuf shadow, grads, heads, descs;
+  size_t grad_count = 0;
+  PassState pass[3];
+  // heads state (fp32)
+  int hN = 0;
+  float *cat[3], *hact[3], *fi[3], *feats = nullptr, *hid = nullptr, *logits = nullptr, *dE[3], *dfeats = nullptr, *dhid = nullptr,
+        *dtmp256 = nullptr, *dtmp512 = nullptr, *dcat = nullptr, *scratch = nullptr, *dlogits = nullptr, *logits_t = nullptr;
+  int last_N = 0, last_npass = 0;
+  bool packed_train = false, packed_eval = false;
+  std::vector<sslcr_tensor_desc> host_descs;
+  std::vector<float*> st1, st2;
+  int ndesc = 0, max_n = 0;
+};
+
+namespace {
+
+const int kBlockCfg[8][3] = {{64, 64, 1}, {64, 64, 1}, {64, 128, 2}, {128, 128, 1}, {128, 256, 2}, {256, 256, 1}, {256, 512, 2}, {512, 512, 1}};
+
+inline int out_dim(int h, int k, int stride, int pad) { return (h + 2 * pad - k) / stride + 1; }
+
+void build_topology(sslcr_net* n) {
+  int p = 0, b = 0;
+  n->stem = ConvL{3, 64, 7, 2, 3, p++};
+  n->bn0 = BnL{64, p, p + 1, b++};
+  p += 2;
+  for (int i = 0; i < 8; ++i) {
+    BlockL& B = n->blocks[i];
+    const int cin = kBlockCfg[i][0], cout = kBlockCfg[i][1], s = kBlockCfg[i][2];
+    B.pstart = p;
+    B.c1 = ConvL{cin, cout, 3, s, 1, p++};
+    B.b1 = BnL{cout, p, p + 1, b++};
+    p += 2;
+    B.c2 = ConvL{cout, cout, 3, 1, 1, p++};
+    B.b2 = BnL{cout, p, p + 1, b++};
+    p += 2;
+    B.has_ds = (s != 1 || cin != cout);
+    if (B.has_ds) {
+      B.ds = ConvL{cin, cout, 1, s, 0, p++};
+      B.bd = BnL{cout, p, p + 1, b++};
+      p += 2;
+    }
+  }
+  // p == 60 ; heads: 60 fc.0.weight [512,1024], 61 fc.0.bias, 62 fc.2.weight [256,512], 63 fc.2.bias, 64.. classifier
+  n->psize.assign(n->nparams, 0);
+  auto conv_sz = [](const ConvL& c) { return c.cout * c.cin * c.k * c.k; };
+  n->psize[n->stem.pidx] = conv_sz(n->stem);
+  n->psize[n->bn0.pg] = n->psize[n->bn0.pb] = 64;
+  for (int i = 0; i < 8; ++i) {
+    BlockL& B = n->blocks[i];
+    n->psize[B.c1.pidx] = conv_sz(B.c1);
+    n->psize[B.c2.pidx] = conv_sz(B.c2);
+    n->psize[B.b1.pg] = n->psize[B.b1.pb] = B.b1.C;
+    n->psize[B.b2.pg] = n->psize[B.b2.pb] = B.b2.C;
+    if (B.has_ds) {
+      n->psize[B.ds.pidx] = conv_sz(B.ds);
+      n->psize[B.bd.pg] = n->psize[B.bd.pb] = B.bd.C;
+    }
+  }
+  n->psize[60] = 512 * 1024;
+  n->psize[61] = 512;
+  n->psize[62] = 256 * 512;
+  n->psize[63] = 256;
+  if (n->head_kind == 0) {
+    n->psize[64] = n->ncls * 768;
+    n->psize[65] = n->ncls;
+  } else {
+    n->psize[64] = 128 * 768;
+    n->psize[65] = 128;
+    n->psize[66] = n->ncls * 128;
+    n->psize[67] = n->ncls;
+  }
+  n->goff.assign(n->nparams + 1, 0);
+  for (int i = 0; i < n->nparams; ++i) n->goff[i + 1] = n->goff[i] + ((n->psize[i] + 63) & ~63);
+  n->grad_count = n->goff[n->nparams];
+}
+
+int alloc_shadow(sslcr_net* n) {
+  const size_t es = n->ctx->esz();
+  Carver c;
+  std::vector<std::pair<ConvL*, size_t>> offs;
+  auto add = [&](ConvL& L) {
+    const size_t wbytes = (L.pidx == 0 ? (size_t)64 * 224 : (size_t)L.cout * L.cin * L.k * L.k) * es;
+    size_t o = c.take(wbytes);          // w_fwd
+    c.take(wbytes);                     // w_dg
+    c.take(wbytes);                     // w_fold
+    c.take(L.cout * sizeof(float));     // b_fold
+    offs.push_back({&L, o});
+  };
+  add(n->stem);
+  for (int i = 0; i < 8; ++i) {
+    add(n->blocks[i].c1);
+    add(n->blocks[i].c2);
+    if (n->blocks[i].has_ds) add(n->blocks[i].ds);
+  }
+  TRYI(n->shadow.ensure(c.off));
+  for (auto& pr : offs) {
+    ConvL& L = *pr.first;
+    const size_t wbytes = ((L.pidx == 0 ? (size_t)64 * 224 : (size_t)L.cout * L.cin * L.k * L.k) * es + 255) & ~(size_t)255;
+    char* base = (char*)n->shadow.p + pr.second;
+    L.w_fwd = base;
+    L.w_dg = base + wbytes;
+    L.w_fold = base + 2 * wbytes;
+    L.b_fold = (float*)(base + 3 * wbytes);
+  }
+  return 0;
+}
+
+int pack_conv_layer(sslcr_net* n, ConvL& L, const BnL& bn, int mode, hipStream_t st) {
+  const int dt = n->ctx->dtype;
+  PackArgs a;
+  memset(&a, 0, sizeof(a));
+  a.w = n->params[L.pidx];
+  a.K = L.cout; a.C = L.cin; a.R = L.k; a.S = L.k;
+  a.eps = 1e-5f;
+  const bool stem = (L.pidx == 0);
+  if (mode & 1) {
+    a.w_fwd = L.w_fwd;
+    a.w_dgrad = stem ? nullptr : L.w_dg;
+    TRY(stem ? launch_pack_stem(dt, a, st) : launch_pack_conv(dt, a, st));
+  }
+  if (mode & 2) {
+    a.w_fwd = L.w_fold;
+    a.w_dgrad = nullptr;
+    a.gamma = n->params[bn.pg]; a.beta = n->params[bn.pb];
+    a.rmean = n->bn_rm[bn.bidx]; a.rvar = n->bn_rv[bn.bidx];
+    a.bias_out = L.b_fold;
+    TRY(stem ? launch_pack_stem(dt, a, st) : launch_pack_conv(dt, a, st));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- BN finalize (optionally synced across ranks)
+int finalize_bn(sslcr_net* n, const BnL& bn, const float* partials, int rows, double local_count, BnSaved& sv, int replay, hipStream_t st) {
+  sslcr_ctx* c = n->ctx;
+  BnFinalizeArgs a;
+  memset(&a, 0, sizeof(a));
+  a.partials = partials; a.rows = rows; a.C = bn.C;
+  a.gamma = n->params[bn.pg]; a.beta = n->params[bn.pb];
+  a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
+  a.running_mean = n->bn_rm[bn.bidx]; a.running_var = n->bn_rv[bn.bidx]; a.num_batches_tracked = n->bn_nbt[bn.bidx];
+  a.momentum = 0.1f; a.eps = 1e-5f; a.replay = replay;
+  a.stage = c->bn_stage;
+  if (c->world > 1) {
+    // global-batch statistics: reduce rows -> [2][C] sums, all-reduce, finalize from the sums
+    BnFinalizeArgs r = a;
+    r.sums_out = c->bn_sums;
+    TRY(launch_bn_finalize(r, st));
+    TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
+    a.sums_in = c->bn_sums;
+    a.count = local_count * c->world;
+  } else {
+    a.count = local_count;
+  }
+  TRY(launch_bn_finalize(a, st));
+  return 0;
+}
+
+ConvArgs conv_args(const ConvL& L, const void* x, const void* w, void* y, int N, int H, int W) {
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.C = L.cin; a.K = L.cout; a.R = L.k; a.S = L.k; a.stride = L.stride; a.pad = L.pad;
+  a.PH = out_dim(H, L.k, L.stride, L.pad); a.PW = out_dim(W, L.k, L.stride, L.pad);
+  a.OH = a.PH; a.OW = a.PW; a.osh = 1;
+  return a;
+}
+
+int ensure_partials(sslcr_ctx* c, const ConvArgs& a, float** out, int* rows) {
+  *rows = conv_partials_rows(a);
+  TRYI(c->partials.ensure((size_t)*rows * 2 * a.K * sizeof(float)));
+  *out = (float*)c->partials.p;
+  return 0;
+}
+
+struct Dims {
+  int oh0, ow0, ph, pw;
+  int lh[8], lw[8];     // OUTPUT spatial dims of each block
+};
+Dims make_dims(int H, int W) {
+  Dims d;
+  d.oh0 = out_dim(H, 7, 2, 3); d.ow0 = out_dim(W, 7, 2, 3);
+  d.ph = out_dim(d.oh0, 3, 2, 1); d.pw = out_dim(d.ow0, 3, 2, 1);
+  int h = d.ph, w = d.pw;
+  for (int i = 0; i < 8; ++i) {
+    const int s = kBlockCfg[i][2];
+    h = out_dim(h, 3, s, 1); w = out_dim(w, 3, s, 1);
+    d.lh[i] = h; d.lw[i] = w;
+  }
+  return d;
+}
+
+int alloc_pass(sslcr_net* n, PassState& ps, int N, int H, int W) {
+  const size_t es = n->ctx->esz();
+  const Dims d = make_dims(H, W);
+  Carver c;
+  const size_t o_raw0 = c.take((size_t)N * d.oh0 * d.ow0 * 64 * es);
+  const size_t o_pool = c.take((size_t)N * d.ph * d.pw * 64 * es);
+  const size_t o_arg = c.take((size_t)N * d.ph * d.pw * 64);
+  size_t o_blk[8][4];
+  for (int i = 0; i < 8; ++i) {
+    const size_t sz = (size_t)N * d.lh[i] * d.lw[i] * kBlockCfg[i][1] * es;
+    for (int j = 0; j < 4; ++j) o_blk[i][j] = (j == 2 && !n->blocks[i].has_ds) ? 0 : c.take(sz);
+  }
+  const size_t o_bn = c.take(20 * 4 * 512 * sizeof(float));
+  const size_t o_E = c.take((size_t)N * 512 * sizeof(float));
+  TRYI(ps.mem.ensure(c.off));
+  char* b = (char*)ps.mem.p;
+  ps.raw0 = b + o_raw0; ps.pooled = b + o_pool; ps.argmax = (uint8_t*)(b + o_arg);
+  for (int i = 0; i < 8; ++i) {
+    ps.blk[i].raw1 = b + o_blk[i][0]; ps.blk[i].raw2 = b + o_blk[i][1];
+    ps.blk[i].rawd = n->blocks[i].has_ds ? b + o_blk[i][2] : nullptr;
+    ps.blk[i].y = b + o_blk[i][3];
+  }
+  float* f = (float*)(b + o_bn);
+  for (int i = 0; i < 20; ++i) {
+    ps.bn[i] = BnSaved{f, f + 512, f + 1024, f + 1536};
+    f += 2048;
+  }
+  ps.E = (float*)(b + o_E);
+  ps.N = N; ps.H = H; ps.W = W;
+  return 0;
+}
+
+// ---------------------------------------------------------------- backbone forward, train mode (saves everything)
+int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f32, int N, int H, int W, int replay, hipStream_t st) {
+  sslcr_ctx* c = n->ctx;
+  const int dt = c->dtype;
+  if (ps.N != N || ps.H != H || ps.W != W || !ps.mem.p) TRYI(alloc_pass(n, ps, N, H, W));
+  ps.x = x; ps.in_f32 = in_f32;
+  const Dims d = make_dims(H, W);
+  {
+    StemArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = n->stem.w_fwd; a.y = ps.raw0;
+    a.N = N; a.H = H; a.W = W; a.OH = d.oh0; a.OW = d.ow0; a.in_f32 = in_f32;
+    const int rows = stem_partials_rows(a);
+    TRYI(c->partials.ensure((size_t)rows * 2 * 64 * sizeof(float)));
+    a.stats = (float*)c->partials.p;
+    TRY(launch_stem(dt, a, st));
+    TRYI(finalize_bn(n, n->bn0, a.stats, rows, (double)N * d.oh0 * d.ow0, ps.bn[0], replay, st));
+    PoolFwdArgs p;
+    memset(&p, 0, sizeof(p));
+    p.x = ps.raw0; p.scale = ps.bn[0].scale; p.shift = ps.bn[0].shift; p.y = ps.pooled; p.argmax = ps.argmax;
+    p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
+    TRY(launch_bn_relu_maxpool(dt, p, st));
+  }
+  const char* X = ps.pooled;
+  int xh = d.ph, xw = d.pw;
+  for (int i = 0; i < 8; ++i) {
+    BlockL& B = n->blocks[i];
+    const int oh = d.lh[i], ow = d.lw[i];
+    float* part; int rows;
+    ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fwd, ps.blk[i].raw1, N, xh, xw);
+    TRYI(ensure_partials(c, a1, &part, &rows));
+    a1.stats = part;
+    TRY(launch_conv(dt, a1, st));
+    TRYI(finalize_bn(n, B.b1, part, rows, (double)N * oh * ow, ps.bn[B.b1.bidx], replay, st));
+    ConvArgs a2 = conv_args(B.c2, ps.blk[i].raw1, B.c2.w_fwd, ps.blk[i].raw2, N, oh, ow);
+    a2.in_scale = ps.bn[B.b1.bidx].scale; a2.in_shift = ps.bn[B.b1.bidx].shift; a2.in_relu = 1;
+    TRYI(ensure_partials(c, a2, &part, &rows));
+    a2.stats = part;
+    TRY(launch_conv(dt, a2, st));
+    TRYI(finalize_bn(n, B.b2, part, rows, (double)N * oh * ow, ps.bn[B.b2.bidx], replay, st));
+    BnActArgs e;
+    memset(&e, 0, sizeof(e));
+    e.x = ps.blk[i].raw2; e.scale = ps.bn[B.b2.bidx].scale; e.shift = ps.bn[B.b2.bidx].shift;
+    e.y = ps.blk[i].y; e.pixels = (size_t)N * oh * ow; e.C = B.c2.cout; e.relu = 1;
+    if (B.has_ds) {
+      ConvArgs ad = conv_args(B.ds, X, B.ds.w_fwd, ps.blk[i].rawd, N, xh, xw);
+      TRYI(ensure_partials(c, ad, &part, &rows));
+      ad.stats = part;
+      TRY(launch_conv(dt, ad, st));
+      TRYI(finalize_bn(n, B.bd, part, rows, (double)N * oh * ow, ps.bn[B.bd.bidx], replay, st));
+      e.res = ps.blk[i].rawd; e.rscale = ps.bn[B.bd.bidx].scale; e.rshift = ps.bn[B.bd.bidx].shift;
+    } else {
+      e.res = X;
+    }
+    TRY(launch_bn_act(dt, e, st));
+    X = ps.blk[i].y; xh = oh; xw = ow;
+  }
+  TRY(launch_avgpool_fwd(dt, X, ps.E, N, xh * xw, 512, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------- backbone forward, eval mode (BN folded, nothing saved)
+int backbone_forward_eval(sslcr_net* n, const void* x, int in_f32, int N, int H, int W, float* E, hipStream_t st) {
+  sslcr_ctx* c = n->ctx;
+  const int dt = c->dtype;
+  const size_t es = c->esz();
+  const Dims d = make_dims(H, W);
+  Carver cv;
+  const size_t o_a0 = cv.take((size_t)N * d.oh0 * d.ow0 * 64 * es);
+  const size_t unit = (size_t)N * d.ph * d.pw * 64 * es;
+  size_t o_buf[4];
+  for (int j = 0; j < 4; ++j) o_buf[j] = cv.take(unit);
+  TRYI(c->scratch.ensure(cv.off));
+  char* base = (char*)c->scratch.p;
+  {
+    StemArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = n->stem.w_fold; a.y = base + o_a0; a.bias = n->stem.b_fold; a.relu = 1;
+    a.N = N; a.H = H; a.W = W; a.OH = d.oh0; a.OW = d.ow0; a.in_f32 = in_f32;
+    TRY(launch_stem(dt, a, st));
+    PoolFwdArgs p;
+    memset(&p, 0, sizeof(p));
+    p.x = base + o_a0; p.scale = c->ones; p.shift = c->zeros; p.y = base + o_buf[0];
+    p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
+    TRY(launch_bn_relu_maxpool(dt, p, st));
+  }
+  int xi = 0, xh = d.ph, xw = d.pw;
+  for (int i = 0; i < 8; ++i) {
+    BlockL& B = n->blocks[i];
+    char* X = base + o_buf[xi];
+    char* t1 = base + o_buf[(xi + 1) & 3];
+    char* td = base + o_buf[(xi + 2) & 3];
+    char* Y = base + o_buf[(xi + 3) & 3];
+    const int oh = d.lh[i], ow = d.lw[i];
+    ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fold, t1, N, xh, xw);
+    a1.bias = B.c1.b_fold; a1.relu = 1;
+    TRY(launch_conv(dt, a1, st));
+    const void* res = X;
+    if (B.has_ds) {
+      ConvArgs ad = conv_args(B.ds, X, B.ds.w_fold, td, N, xh, xw);
+      ad.bias = B.ds.b_fold;
+      TRY(launch_conv(dt, ad, st));
+      res = td;
+    }
+    ConvArgs a2 = conv_args(B.c2, t1, B.c2.w_fold, Y, N, oh, ow);
+    a2.bias = B.c2.b_fold; a2.residual = res; a2.relu = 1;
+    TRY(launch_conv(dt, a2, st));
+    xi = (xi + 3) & 3; xh = oh; xw = ow;
+  }
+  TRY(launch_avgpool_fwd(dt, base + o_buf[xi], E, N, xh * xw, 512, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------- heads
+int alloc_heads(sslcr_net* n, int N) {
+  if (n->hN >= N && n->heads.p) return 0;
+  Carver c;
+  size_t o_cat[3], o_h[3], o_f[3], o_dE[3];
+  for (int i = 0; i < 3; ++i) {
+    o_cat[i] = c.take((size_t)N * 1024 * 4); o_h[i] = c.take((size_t)N * 512 * 4);
+    o_f[i] = c.take((size_t)N * 256 * 4); o_dE[i] = c.take((size_t)N * 512 * 4);
+  }
+  const size_t o_feats = c.take((size_t)N * 768 * 4), o_hid = c.take((size_t)N * 128 * 4), o_log = c.take((size_t)N * 64 * 4);
+  const size_t o_dfeats = c.take((size_t)N * 768 * 4), o_dhid = c.take((size_t)N * 128 * 4);
+  const size_t o_d256 = c.take((size_t)N * 256 * 4), o_d512 = c.take((size_t)N * 512 * 4), o_dcat = c.take((size_t)N * 1024 * 4);
+  const size_t o_scr = c.take((size_t)N * 1024 * 4), o_dl = c.take((size_t)N * 64 * 4), o_lt = c.take((size_t)N * 64 * 4);
+  TRYI(n->heads.ensure(c.off));
+  char* b = (char*)n->heads.p;
+  for (int i = 0; i < 3; ++i) {
+    n->cat[i] = (float*)(b + o_cat[i]); n->hact[i] = (float*)(b + o_h[i]);
+    n->fi[i] = (float*)(b + o_f[i]); n->dE[i] = (float*)(b + o_dE[i]);
+  }
+  n->feats = (float*)(b + o_feats); n->hid = (float*)(b + o_hid); n->logits = (float*)(b + o_log);
+  n->dfeats = (float*)(b + o_dfeats); n->dhid = (float*)(b + o_dhid);
+  n->dtmp256 = (float*)(b + o_d256); n->dtmp512 = (float*)(b + o_d512); n->dcat = (float*)(b + o_dcat);
+  n->scratch = (float*)(b + o_scr); n->dlogits = (float*)(b + o_dl); n->logits_t = (float*)(b + o_lt);
+  n->hN = N;
+  return 0;
+}
+
+const int kPairs[3][2] = {{0, 1}, {1, 2}, {0, 2}};     // E12, E23, E13 (models/net.py:56-58)
+
+// E[0..npass-1] -> feats [N,768], logits [N,C]
+int heads_forward(sslcr_net* n, float* const* E, int npass, int N, hipStream_t st) {
+  const float *w0 = n->params[60], *b0 = n->params[61], *w2 = n->params[62], *b2 = n->params[63];
+  const int nh = (npass == 3) ? 3 : 1;
+  for (int i = 0; i < nh; ++i) {
+    const float* Ea = E[npass == 3 ? kPairs[i][0] : 0];
+    const float* Eb = E[npass == 3 ? kPairs[i][1] : 0];
+    TRY(launch_copy2d(n->cat[i], 1024, Ea, 512, N, 512, 0, st));
+    TRY(launch_copy2d(n->cat[i] + 512, 1024, Eb, 512, N, 512, 0, st));
+    TRY(launch_linear_fwd(n->cat[i], w0, b0, n->hact[i], N, 512, 1024, 1, st));
+    TRY(launch_linear_fwd(n->hact[i], w2, b2, n->fi[i], N, 256, 512, 0, st));
+  }
+  for (int i = 0; i < 3; ++i) TRY(launch_copy2d(n->feats + 256 * i, 768, n->fi[nh == 3 ? i : 0], 256, N, 256, 0, st));
+  if (n->head_kind == 0) {
+    TRY(launch_linear_fwd(n->feats, n->params[64], n->params[65], n->logits, N, n->ncls, 768, 0, st));
+  } else {
+    TRY(launch_linear_fwd(n->feats, n->params[64], n->params[65], n->hid, N, 128, 768, 1, st));
+    TRY(launch_linear_fwd(n->hid, n->params[66], n->params[67], n->logits, N, n->ncls, 128, 0, st));
+  }
+  return 0;
+}
+
+inline float* gptr(sslcr_net* n, int pidx) { return n->rg[pidx] ? (float*)n->grads.p + n->goff[pidx] : nullptr; }
+
+// dlogits -> head parameter grads and dE[0..npass-1]
+int heads_backward(sslcr_net* n, const float* dlogits, int npass, int N, bool need_dE, hipStream_t st) {
+  const float *w0 = n->params[60], *w2 = n->params[62];
+  const bool any_fc = n->rg[60] || n->rg[61] || n->rg[62] || n->rg[63];
+  if (n->head_kind == 0) {
+    TRY(launch_linear_bwd(n->feats, n->params[64], dlogits, nullptr, (any_fc || need_dE) ? n->dfeats : nullptr, gptr(n, 64), gptr(n, 65),
+                          N, n->ncls, 768, 0, n->scratch, st));
+  } else {
+    TRY(launch_linear_bwd(n->hid, n->params[66], dlogits, nullptr, n->dhid, gptr(n, 66), gptr(n, 67), N, n->ncls, 128, 0, n->scratch, st));
+    TRY(launch_linear_bwd(n->feats, n->params[64], n->dhid, n->hid, (any_fc || need_dE) ? n->dfeats : nullptr, gptr(n, 64), gptr(n, 65),
+                          N, 128, 768, 0, n->scratch, st));
+  }
+  if (!any_fc && !need_dE) return 0;
+  const int nh = (npass == 3) ? 3 : 1;
+  if (need_dE)
+    for (int i = 0; i < npass; ++i) TRY(hipMemsetAsync(n->dE[i], 0, (size_t)N * 512 * 4, st));
+  for (int i = 0; i < nh; ++i) {
+    if (nh == 3) {
+      TRY(launch_copy2d(n->dtmp256, 256, n->dfeats + 256 * i, 768, N, 256, 0, st));
+    } else {   // the three identical branches of TripletNet_Finetune: gradients add (models/net.py:96-100)
+      for (int j = 0; j < 3; ++j) TRY(launch_copy2d(n->dtmp256, 256, n->dfeats + 256 * j, 768, N, 256, j > 0, st));
+    }
+    TRY(launch_linear_bwd(n->hact[i], w2, n->dtmp256, nullptr, n->dtmp512, gptr(n, 62), gptr(n, 63), N, 256, 512, 0, n->scratch, st));
+    TRY(launch_linear_bwd(n->cat[i], w0, n->dtmp512, n->hact[i], need_dE ? n->dcat : nullptr, gptr(n, 60), gptr(n, 61), N, 512, 1024, 0,
+                          n->scratch, st));
+    if (need_dE) {
+      const int a = nh == 3 ? kPairs[i][0] : 0, b = nh == 3 ? kPairs[i][1] : 0;
+      TRY(launch_copy2d(n->dE[a], 512, n->dcat, 1024, N, 512, 1, st));
+      TRY(launch_copy2d(n->dE[b], 512, n->dcat + 512, 1024, N, 512, 1, st));
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- backbone backward for one saved pass
+int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
+                void* dx, void* gout, size_t pixels, double count, hipStream_t st) {
+  sslcr_ctx* c = n->ctx;
+  BnBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dy = dy; a.x = x; a.yact = yact; a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
+  a.sums = c->bn_sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
+  a.count = count * c->world;
+  TRY(hipMemsetAsync(c->bn_sums, 0, 2 * bn.C * sizeof(double), st));
+  TRY(launch_bn_bwd_reduce(c->dtype, a, st));
+  if (c->world > 1) TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
+  TRY(launch_bn_bwd_apply(c->dtype, a, st));
+  if (n->rg[bn.pg] || n->rg[bn.pb]) {
+    // dgamma/dbeta: with synced BN the sums are already global -> scale so that the later grad all-reduce(sum)/world is right
+    float* dg = gptr(n, bn.pg);
+    float* db = gptr(n, bn.pb);
+    // synced BN: every rank holds the GLOBAL sums and the gradient all-reduce adds `world` copies -> pre-divide
+    if (dg && db) TRY(launch_bn_param_grads_scaled(c->bn_sums, sv.invstd, dg, db, bn.C, 1.0f / c->world, st));
+  }
+  return 0;
+}
+
+int wgrad_call(sslcr_net* n, const ConvL& L, const void* x, const void* dy, const BnSaved* pro, int N, int H, int W, int OH, int OW, hipStream_t st) {
+  if (!n->rg[L.pidx]) return 0;
+  WgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.dy = dy; a.dw = (float*)n->grads.p + n->goff[L.pidx];
+  if (pro) { a.in_scale = pro->scale; a.in_shift = pro->shift; a.in_relu = 1; }
+  a.N = N; a.H = H; a.W = W; a.C = L.cin; a.K = L.cout; a.R = L.k; a.S = L.k; a.stride = L.stride; a.pad = L.pad; a.OH = OH; a.OW = OW;
+  TRY(launch_wgrad(n->ctx->dtype, a, st));
+  return 0;
+}
+
+int launch_bucket_allreduce(sslcr_net* n, int bucket, size_t lo, size_t hi, hipStream_t st) {
+  sslcr_ctx* c = n->ctx;
+  if (c->world <= 1 || hi <= lo) return 0;
+  TRY(hipEventRecord(c->ev_ready[bucket], st));
+  TRY(hipStreamWaitEvent(c->comm_stream, c->ev_ready[bucket], 0));
+  float* g = (float*)n->grads.p + lo;
+  TRYN(ncclAllReduce(g, g, hi - lo, ncclFloat, ncclSum, c->comm, c->comm_stream));
+  return 0;
+}
+
+// lowest parameter index that requires grad in the backbone (60 if none)
+int lowest_trainable(const sslcr_net* n) {
+  for (int i = 0; i < 60; ++i)
+    if (n->rg[i]) return i;
+  return 60;
+}
+
+int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pass, hipStream_t st) {
+  sslcr_ctx* c = n->ctx;
+  const int dt = c->dtype;
+  const size_t es = c->esz();
+  const int N = ps.N;
+  const Dims d = make_dims(ps.H, ps.W);
+  const int low = lowest_trainable(n);
+  if (low >= 60) return 0;
+  // transient buffers: bufA = {dOut, G, dRaw2, dAct1} ; bufB = {dRaw1, dXin, dRawD, -}; each slot one layer1-sized unit;
+  // the stem uses all of A (g0) then all of B (dRaw0)
+  const size_t unit = (((size_t)N * d.ph * d.pw * 64 * es) + 255) & ~(size_t)255;
+  const size_t stem_sz = (size_t)N * d.oh0 * d.ow0 * 64 * es;
+  const size_t half = (4 * unit > stem_sz) ? 4 * unit : ((stem_sz + 255) & ~(size_t)255);
+  TRYI(c->scratch.ensure(2 * half));
+  char* A = (char*)c->scratch.p;
+  char* Bf = A + half;
+  char *dOut = A, *G = A + unit, *dRaw2 = A + 2 * unit, *dAct1 = A + 3 * unit;
+  char *dRaw1 = Bf, *dXin = Bf + unit, *dRawD = Bf + 2 * unit;
+
+  size_t hi_pending = n->goff[60];
+  int bucket = 1;
+  TRY(launch_avgpool_bwd(dt, dE, dOut, N, d.lh[7] * d.lw[7], 512, st));
+  for (int i = 7; i >= 0; --i) {
+    BlockL& B = n->blocks[i];
+    const int oh = d.lh[i], ow = d.lw[i];
+    const int xh = i == 0 ? d.ph : d.lh[i - 1], xw = i == 0 ? d.pw : d.lw[i - 1];
+    const char* X = i == 0 ? ps.pooled : ps.blk[i - 1].y;
+    const size_t opix = (size_t)N * oh * ow;
+    const bool need_dx = low < B.pstart;          // something upstream of this block is trainable
+    // bn2 (+ relu mask from the block output) ; G = masked gradient feeds the identity path
+    TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, (!B.has_ds && need_dx) ? G : nullptr, opix,
+                     (double)opix, st));
+    if (B.has_ds)
+      TRYI(bn_backward(n, B.bd, ps.bn[B.bd.bidx], dOut, ps.blk[i].rawd, ps.blk[i].y, 0, dRawD, nullptr, opix, (double)opix, st));
+    TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
+    {
+      ConvArgs a = conv_args(B.c2, dRaw2, B.c2.w_dg, dAct1, N, oh, ow);      // dgrad 3x3/1: gather over dRaw2 [.,K] with [C][R][S][K]
+      a.C = B.c2.cout; a.K = B.c2.cin; a.transposed = 1; a.PH = oh; a.PW = ow; a.OH = oh; a.OW = ow;
+      TRY(launch_conv(dt, a, st));
+    }
+    TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, 1, dRaw1, nullptr, opix, (double)opix, st));
+    TRYI(wgrad_call(n, B.c1, X, dRaw1, nullptr, N, xh, xw, oh, ow, st));
+    if (B.has_ds) TRYI(wgrad_call(n, B.ds, X, dRawD, nullptr, N, xh, xw, oh, ow, st));
+    if (need_dx) {
+      ConvArgs a = conv_args(B.c1, dRaw1, B.c1.w_dg, dXin, N, oh, ow);
+      a.C = B.c1.cout; a.K = B.c1.cin; a.transposed = 1; a.PH = xh; a.PW = xw; a.OH = xh; a.OW = xw;
+      if (!B.has_ds) a.residual = G;
+      TRY(launch_conv(dt, a, st));
+      if (B.has_ds) {       // 1x1/2 projection: scatter-accumulate into the even positions of dXin
+        ConvArgs s = conv_args(B.ds, dRawD, B.ds.w_dg, dXin, N, oh, ow);
+        s.C = B.ds.cout; s.K = B.ds.cin; s.stride = 1; s.pad = 0; s.PH = oh; s.PW = ow; s.OH = xh; s.OW = xw; s.osh = B.ds.stride;
+        s.accumulate = 1;
+        TRY(launch_conv(dt, s, st));
+      }
+      char* t = dOut; dOut = dXin; dXin = t;        // ping-pong: this block's input gradient is the next dOut
+    }
+    if (last_pass && (i == 6 || i == 4 || i == 2)) {   // layer4 / layer3 / layer2 gradients are final: reduce them under the rest of backward
+      TRYI(launch_bucket_allreduce(n, bucket++, n->goff[B.pstart], hi_pending, st));
+      hi_pending = n->goff[B.pstart];
+    }
+    if (!need_dx) break;
+  }
+  if (low < 3) {
+    // stem: maxpool+relu backward -> bn0 backward -> conv1 wgrad (no dgrad: the input is data)
+    PoolBwdArgs p;
+    memset(&p, 0, sizeof(p));
+    // dOut (= dP) sits in one half of the scratch: g0 takes the other half, dRaw0 then overwrites dP's half
+    // (stream order: the pool backward has consumed dP by then)
+    char* dp_half = (dOut >= Bf) ? Bf : A;
+    char* g0 = (dp_half == A) ? Bf : A;
+    char* dRaw0 = dp_half;
+    p.dy = dOut; p.argmax = ps.argmax; p.x = ps.raw0; p.scale = ps.bn[0].scale; p.shift = ps.bn[0].shift; p.dx = g0;
+    p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
+    TRY(launch_maxpool_relu_bwd(dt, p, st));
+    const size_t spix = (size_t)N * d.oh0 * d.ow0;
+    TRYI(bn_backward(n, n->bn0, ps.bn[0], g0, ps.raw0, nullptr, 0, dRaw0, nullptr, spix, (double)spix, st));
+    if (n->rg[0]) {
+      StemWgradArgs w;
+      memset(&w, 0, sizeof(w));
+      w.x = ps.x; w.dy = dRaw0; w.dw = (float*)n->grads.p + n->goff[0];
+      w.N = N; w.H = ps.H; w.W = ps.W; w.OH = d.oh0; w.OW = d.ow0; w.in_f32 = ps.in_f32;
+      TRY(launch_stem_wgrad(dt, w, st));
+    }
+  }
+  if (last_pass) TRYI(launch_bucket_allreduce(n, bucket, 0, hi_pending, st));
+  return 0;
+}
+
+int net_forward(sslcr_net* n, int train, const void* const* xs, int in_f32, int N, int H, int W, float* feats, float* logits, hipStream_t st) {
+  if (!(train ? n->packed_train : n->packed_eval)) TRYI(sslcr_net_pack(n, train ? 1 : 2, st));   // shadow weights are stale
+  if (train) n->packed_eval = false;               // running statistics are about to change
+  const int npass = n->triplet ? 3 : 1;
+  TRYI(alloc_heads(n, N));
+  float* E[3] = {nullptr, nullptr, nullptr};
+  for (int i = 0; i < npass; ++i) {
+    if (train) {
+      TRYI(backbone_forward_train(n, n->pass[i], xs[i], in_f32, N, H, W, n->triplet ? 1 : 3, st));
+      E[i] = n->pass[i].E;
+    } else {
+      E[i] = n->dE[i];         // borrow the dE buffers (unused in eval) for the embeddings
+      TRYI(backbone_forward_eval(n, xs[i], in_f32, N, H, W, E[i], st));
+    }
+  }
+  TRYI(heads_forward(n, E, npass, N, st));
+  if (feats) TRY(hipMemcpyAsync(feats, n->feats, (size_t)N * 768 * 4, hipMemcpyDeviceToDevice, st));
+  if (logits) TRY(hipMemcpyAsync(logits, n->logits, (size_t)N * n->ncls * 4, hipMemcpyDeviceToDevice, st));
+  n->last_N = N; n->last_npass = train ? npass : 0;
+  return 0;
+}
+
+int net_backward(sslcr_net* n, const float* dlogits, hipStream_t st) {
+  sslcr_ctx* c = n->ctx;
+  if (n->last_npass == 0) return fail("sslcr_net_backward: no train-mode forward to differentiate");
+  const int N = n->last_N, npass = n->last_npass;
+  TRYI(n->grads.ensure(n->grad_count * sizeof(float)));
+  TRY(hipMemsetAsync(n->grads.p, 0, n->grad_count * sizeof(float), st));
+  const bool bb = lowest_trainable(n) < 60;
+  TRYI(heads_backward(n, dlogits, npass, N, bb, st));
+  TRYI(launch_bucket_allreduce(n, 0, n->goff[60], n->goff[n->nparams], st));
+  if (bb) {
+    for (int i = npass - 1; i >= 0; --i) TRYI(backbone_backward(n, n->pass[i], n->dE[i], i == 0, st));
+  }
+  if (c->world > 1) {
+    TRY(hipEventRecord(c->ev_done, c->comm_stream));
+    TRY(hipStreamWaitEvent(st, c->ev_done, 0));
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sslcr_create(sslcr_ctx** out, int device, int dtype) {
+  if (!out || (dtype != SSLCR_F32 && dtype != SSLCR_BF16)) return fail("sslcr_create: invalid argument");
+  TRY(hipSetDevice(device));
+  sslcr_ctx* c = new sslcr_ctx();
+  c->device = device; c->dtype = dtype;
+  if (c->small.ensure(32 * 2 * 512 * sizeof(double) + 2 * 512 * sizeof(double) + 2 * 512 * sizeof(float)) != 0) { delete c; return -1; }
+  c->bn_stage = (double*)c->small.p;
+  c->bn_sums = c->bn_stage + 32 * 2 * 512;
+  c->ones = (float*)(c->bn_sums + 2 * 512);
+  c->zeros = c->ones + 512;
+  TRY(launch_fill(c->ones, 512, 1.f, nullptr));
+  TRY(launch_fill(c->zeros, 512, 0.f, nullptr));
+  TRY(hipStreamSynchronize(nullptr));
+  *out = c;
+  return 0;
+}
+
+int sslcr_destroy(sslcr_ctx* c) {
+  if (!c) return 0;
+  (void)hipDeviceSynchronize();
+  if (c->comm) {
+    ncclCommDestroy(c->comm);
+    (void)hipStreamDestroy(c->comm_stream);
+    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev_ready[i]);
+    (void)hipEventDestroy(c->ev_done);
+  }
+  c->scratch.release(); c->partials.release(); c->small.release();
+  delete c;
+  return 0;
+}
+
+int sslcr_comm_unique_id(void* id128) {
+  if (!id128) return fail("sslcr_comm_unique_id: null");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  TRYN(ncclGetUniqueId((ncclUniqueId*)id128));
+  return 0;
+}
+
+int sslcr_comm_init(sslcr_ctx* c, const void* id128, int rank, int world) {
+  if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail("sslcr_comm_init: invalid argument");
+  if (world == 1) { c->rank = 0; c->world = 1; return 0; }
+  TRY(hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  TRYN(ncclCommInitRank(&c->comm, world, id, rank));
+  TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; ++i) TRY(hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming));
+  TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  c->rank = rank; c->world = world;
+  return 0;
+}
+
+int sslcr_net_create(sslcr_ctx* c, const sslcr_net_desc* d, sslcr_net** out) {
+  if (!c || !d || !out || !d->params) return fail("sslcr_net_create: null");
+  const int want = 64 + (d->head_kind == 0 ? 2 : 4);
+  if (d->nparams != want) return fail("sslcr_net_create: expected %d parameters (64 net + classifier), got %d", want, d->nparams);
+  if (d->num_classes < 1 || d->num_classes > 64) return fail("sslcr_net_create: num_classes out of range");
+  sslcr_net* n = new sslcr_net();
+  n->ctx = c; n->nparams = d->nparams; n->head_kind = d->head_kind; n->ncls = d->num_classes; n->triplet = d->triplet;
+  n->params.assign(d->params, d->params + d->nparams);
+  n->rg.assign(d->nparams, 1);
+  if (d->requires_grad) n->rg.assign(d->requires_grad, d->requires_grad + d->nparams);
+  for (int i = 0; i < 20; ++i) {
+    n->bn_rm[i] = d->bn_running_mean[i]; n->bn_rv[i] = d->bn_running_var[i];
+    n->bn_nbt[i] = d->bn_num_batches_tracked ? d->bn_num_batches_tracked[i] : nullptr;
+  }
+  build_topology(n);
+  if (alloc_shadow(n) != 0) { delete n; return -1; }
+  *out = n;
+  return 0;
+}
+
+int sslcr_net_destroy(sslcr_net* n) {
+  if (!n) return 0;
+  (void)hipDeviceSynchronize();
+  n->shadow.release(); n->grads.release(); n->heads.release(); n->descs.release();
+  for (int i = 0; i < 3; ++i) n->pass[i].mem.release();
+  delete n;
+  return 0;
+}
+
+int sslcr_net_set_requires_grad(sslcr_net* n, const uint8_t* flags) {
+  if (!n || !flags) return fail("sslcr_net_set_requires_grad: null");
+  n->rg.assign(flags, flags + n->nparams);
+  n->ndesc = 0;
+  return 0;
+}
+
+int sslcr_net_pack(sslcr_net* n, int mode, void* stream) {
+  if (!n || !(mode & 3)) return fail("sslcr_net_pack: invalid argument");
+  hipStream_t st = (hipStream_t)stream;
+  TRYI(pack_conv_layer(n, n->stem, n->bn0, mode, st));
+  for (int i = 0; i < 8; ++i) {
+    BlockL& B = n->blocks[i];
+    TRYI(pack_conv_layer(n, B.c1, B.b1, mode, st));
+    TRYI(pack_conv_layer(n, B.c2, B.b2, mode, st));
+    if (B.has_ds) TRYI(pack_conv_layer(n, B.ds, B.bd, mode, st));
+  }
+  if (mode & 1) n->packed_train = true;
+  if (mode & 2) n->packed_eval = true;
+  return 0;
+}
+
+int sslcr_net_forward(sslcr_net* n, int train, const void* x1, const void* x2, const void* x3, int in_f32, int N, int H, int W,
+                      float* feats, float* logits, void* stream) {
+  if (!n || !x1 || N < 1 || H < 32 || W < 32) return fail("sslcr_net_forward: invalid argument");
+  if (n->triplet && (!x2 || !x3)) return fail("sslcr_net_forward: TripletNet needs three inputs");
+  const void* xs[3] = {x1, x2, x3};
+  return net_forward(n, train, xs, in_f32, N, H, W, feats, logits, (hipStream_t)stream);
+}
+
+int sslcr_net_backward(sslcr_net* n, const float* dlogits, void* stream) {
+  if (!n || !dlogits) return fail("sslcr_net_backward: null");
+  return net_backward(n, dlogits, (hipStream_t)stream);
+}
+
+int sslcr_net_grad(sslcr_net* n, int pidx, float* out, void* stream) {
+  if (!n || !out || pidx < 0 || pidx >= n->nparams) return fail("sslcr_net_grad: invalid argument");
+  if (!n->grads.p) return fail("sslcr_net_grad: no backward has run");
+  hipStream_t st = (hipStream_t)stream;
+  const float* g = (const float*)n->grads.p + n->goff[pidx];
+  const ConvL* L = nullptr;
+  for (int i = 0; i < 8 && !L; ++i) {
+    BlockL& B = n->blocks[i];
+    if (B.c1.pidx == pidx) L = &B.c1;
+    else if (B.c2.pidx == pidx) L = &B.c2;
+    else if (B.has_ds && B.ds.pidx == pidx) L = &B.ds;
+  }
+  if (L) {
+    TRY(launch_unpack_grad(g, out, L->cout, L->cin, L->k * L->k, st));
+  } else {
+    TRY(hipMemcpyAsync(out, g, (size_t)n->psize[pidx] * 4, hipMemcpyDeviceToDevice, st));
+  }
+  return 0;
+}
+
+int sslcr_net_optimizer_step(sslcr_net* n, const sslcr_opt_desc* o, float* const* s1, float* const* s2, void* stream) {
+  if (!n || !o || !s1) return fail("sslcr_net_optimizer_step: null");
+  if (!n->grads.p) return fail("sslcr_net_optimizer_step: no gradients (run a backward first)");
+  hipStream_t st = (hipStream_t)stream;
+  // (re)build the device descriptor table when the state pointers or the trainable set changed
+  bool rebuild = n->ndesc == 0 || (int)n->st1.size() != n->nparams;
+  if (!rebuild)
+    for (int i = 0; i < n->nparams; ++i)
+      if (n->st1[i] != s1[i] || n->st2[i] != (s2 ? s2[i] : nullptr)) { rebuild = true; break; }
+  if (rebuild) {
+    n->host_descs.clear();
+    n->max_n = 0;
+    for (int i = 0; i < n->nparams; ++i) {
+      if (!n->rg[i]) continue;
+      if (!s1[i] || (o->kind == 0 && (!s2 || !s2[i]))) return fail("sslcr_net_optimizer_step: missing optimizer state for parameter %d", i);
+      sslcr_tensor_desc t;
+      memset(&t, 0, sizeof(t));
+      t.p = n->params[i]; t.g = (float*)n->grads.p + n->goff[i]; t.s1 = s1[i]; t.s2 = s2 ? s2[i] : nullptr; t.n = n->psize[i];
+      for (int b = 0; b < 8; ++b) {
+        BlockL& B = n->blocks[b];
+        const ConvL* L = B.c1.pidx == i ? &B.c1 : B.c2.pidx == i ? &B.c2 : (B.has_ds && B.ds.pidx == i) ? &B.ds : nullptr;
+        if (L) { t.K = L->cout; t.C = L->cin; t.RS = L->k * L->k; }
+      }
+      n->host_descs.push_back(t);
+      if (t.n > n->max_n) n->max_n = t.n;
+    }
+    n->ndesc = (int)n->host_descs.size();
+    if (n->ndesc == 0) return 0;
+    TRYI(n->descs.ensure(n->ndesc * sizeof(sslcr_tensor_desc)));
+    TRY(hipMemcpyAsync(n->descs.p, n->host_descs.data(), n->ndesc * sizeof(sslcr_tensor_desc), hipMemcpyHostToDevice, st));
+    TRY(hipStreamSynchronize(st));       // host_descs may be rebuilt before the copy would otherwise land
+    n->st1.assign(s1, s1 + n->nparams);
+    if (s2) n->st2.assign(s2, s2 + n->nparams); else n->st2.assign(n->nparams, nullptr);
+  }
+  if (n->ndesc == 0) return 0;
+  // sharded runs: every rank's loss is already scaled by 1/(global batch), so the all-reduced SUM is the exact gradient
+  TRY(launch_optimizer((const sslcr_tensor_desc*)n->descs.p, n->ndesc, n->max_n, *o, st));
+  n->packed_train = false; n->packed_eval = false;
+  return 0;
+}
+
+int sslcr_net_lookahead(sslcr_net* n, float* const* cached, float alpha, void* stream) {
+  if (!n || !cached) return fail("sslcr_net_lookahead: null");
+  for (int i = 0; i < n->nparams; ++i)
+    if (cached[i]) TRY(launch_axpby(n->params[i], cached[i], n->psize[i], alpha, 1, (hipStream_t)stream));
+  n->packed_train = false; n->packed_eval = false;
+  return 0;
+}
+
+int sslcr_net_ema_from(sslcr_net* t, sslcr_net* s, float decay, void* stream) {
+  if (!t || !s || t->nparams != s->nparams) return fail("sslcr_net_ema_from: mismatched nets");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < t->nparams; ++i) TRY(launch_axpby(t->params[i], s->params[i], t->psize[i], decay, 0, st));
+  // BN buffers are copied (deepcopy semantics for running statistics)
+  TRY(hipMemcpyAsync(t->bn_rm[0], s->bn_rm[0], 64 * 4, hipMemcpyDeviceToDevice, st));
+  TRY(hipMemcpyAsync(t->bn_rv[0], s->bn_rv[0], 64 * 4, hipMemcpyDeviceToDevice, st));
+  if (t->bn_nbt[0] && s->bn_nbt[0]) TRY(hipMemcpyAsync(t->bn_nbt[0], s->bn_nbt[0], 8, hipMemcpyDeviceToDevice, st));
+  for (int b = 0; b < 8; ++b) {
+    BlockL& B = t->blocks[b];
+    const BnL* bns[3] = {&B.b1, &B.b2, B.has_ds ? &B.bd : nullptr};
+    for (const BnL* bn : bns) {
+      if (!bn) continue;
+      TRY(hipMemcpyAsync(t->bn_rm[bn->bidx], s->bn_rm[bn->bidx], bn->C * 4, hipMemcpyDeviceToDevice, st));
+      TRY(hipMemcpyAsync(t->bn_rv[bn->bidx], s->bn_rv[bn->bidx], bn->C * 4, hipMemcpyDeviceToDevice, st));
+      if (t->bn_nbt[bn->bidx] && s->bn_nbt[bn->bidx])
+        TRY(hipMemcpyAsync(t->bn_nbt[bn->bidx], s->bn_nbt[bn->bidx], 8, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  t->packed_train = false; t->packed_eval = false;
+  return 0;
+}
+
+int sslcr_step_ssl_cr(sslcr_net* te, sslcr_net* stn, const sslcr_ssl_cr_desc* d, void* stream) {
+  if (!te || !stn || !d || !d->x_student || !d->x_teacher || !d->losses) return fail("sslcr_step_ssl_cr: null");
+  if (d->nx < 1 || d->nu < 1) return fail("sslcr_step_ssl_cr: nx, nu must be positive");
+  if (te->ncls != stn->ncls) return fail("sslcr_step_ssl_cr: teacher/student class count differ");
+  hipStream_t st = (hipStream_t)stream;
+  const int Ns = d->nx + d->nu;
+  TRYI(alloc_heads(stn, Ns));
+  // teacher: eval + no_grad (eval_BreastPathQ_SSL_CR.py:43-44,77-79)
+  const void* xt[3] = {d->x_teacher, nullptr, nullptr};
+  TRYI(net_forward(te, 0, xt, d->in_f32, d->nu, d->H, d->W, nullptr, stn->logits_t, st));
+  // student: train mode on cat(x, u_s) (:82-84)
+  const void* xs[3] = {d->x_student, nullptr, nullptr};
+  TRYI(net_forward(stn, 1, xs, d->in_f32, Ns, d->H, d->W, d->feats, d->logits, st));
+  LossArgs L;
+  memset(&L, 0, sizeof(L));
+  L.kind = d->kind; L.logits = stn->logits; L.logits_t = stn->logits_t; L.target_f = d->target_f; L.target_i = d->target_i;
+  L.dlogits = d->backward ? stn->dlogits : nullptr; L.out = d->losses; L.nx = d->nx; L.nu = d->nu; L.C = stn->ncls; L.lambda_u = d->lambda_u;
+  L.inv_nx_global = 1.f / (float)(d->nx_global > 0 ? d->nx_global : d->nx);
+  L.inv_nu_global = 1.f / (float)(d->nu_global > 0 ? d->nu_global : d->nu);
+  if (d->kind == 0 && !d->target_f) return fail("sslcr_step_ssl_cr: mse needs target_f");
+  if (d->kind == 1 && !d->target_i) return fail("sslcr_step_ssl_cr: ce needs target_i");
+  TRY(launch_loss(L, st));
+  if (d->logits_t) TRY(hipMemcpyAsync(d->logits_t, stn->logits_t, (size_t)d->nu * stn->ncls * 4, hipMemcpyDeviceToDevice, st));
+  if (d->backward) TRYI(net_backward(stn, stn->dlogits, st));
+  return 0;
+}
+
+int sslcr_step_supervised(sslcr_net* n, const sslcr_sup_desc* d, void* stream) {
+  if (!n || !d || !d->x1 || !d->losses) return fail("sslcr_step_supervised: null");
+  if (d->kind != 2 && d->kind != 3) return fail("sslcr_step_supervised: kind must be 2 (ce) or 3 (mse)");
+  if (n->triplet && (!d->x2 || !d->x3)) return fail("sslcr_step_supervised: TripletNet needs three inputs");
+  hipStream_t st = (hipStream_t)stream;
+  const void* xs[3] = {d->x1, d->x2, d->x3};
+  TRYI(net_forward(n, d->train, xs, d->in_f32, d->n, d->H, d->W, d->feats, d->logits, st));
+  LossArgs L;
+  memset(&L, 0, sizeof(L));
+  L.kind = d->kind; L.logits = n->logits; L.target_f = d->target_f; L.target_i = d->target_i;
+  L.dlogits = (d->train && d->backward) ? n->dlogits : nullptr; L.out = d->losses; L.nx = d->n; L.nu = 0; L.C = n->ncls;
+  L.inv_nx_global = 1.f / (float)(d->n_global > 0 ? d->n_global : d->n); L.inv_nu_global = 1.f;
+  if (d->kind == 3 && !d->target_f) return fail("sslcr_step_supervised: mse needs target_f");
+  if (d->kind == 2 && !d->target_i) return fail("sslcr_step_supervised: ce needs target_i");
+  TRY(launch_loss(L, st));
+  if (d->train && d->backward) TRYI(net_backward(n, n->dlogits, st));
+  return 0;
+}
+
+}  // extern "C"

@@ -41,6 +41,7 @@ hipError_t launch_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int H
 hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st);
 hipError_t launch_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, hipStream_t st);
+hipError_t launch_bn_param_grads_scaled(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, float scale, hipStream_t st);
 // heads.hip
 hipError_t launch_linear_fwd(const float* x, const float* w, const float* b, float* y, int M, int N, int K, int relu, hipStream_t st);
 hipError_t launch_linear_bwd(const float* x, const float* w, const float* dy, const float* yact, float* dx, float* dw, float* db,
@@ -52,5 +53,10 @@ hipError_t launch_axpby(float* p, float* q, size_t n, float alpha, int copy_back
 hipError_t launch_fill(float* p, size_t n, float v, hipStream_t st);
 hipError_t launch_pack_conv(int dtype, const PackArgs& a, hipStream_t st);
 hipError_t launch_pack_stem(int dtype, const PackArgs& a, hipStream_t st);
+hipError_t launch_copy2d(float* dst, long ldd, const float* src, long lds, int rows, int w, int accumulate, hipStream_t st);
+hipError_t launch_unpack_grad(const float* g, float* out, int K, int C, int RS, hipStream_t st);
+// capi.cpp
+int fail(const char* fmt, ...);
+int check(hipError_t e, const char* what);
 
 }  // namespace sslcr

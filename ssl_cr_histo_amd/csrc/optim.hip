@@ -132,3 +132,41 @@ hipError_t launch_pack_stem(int dtype, const PackArgs& a, hipStream_t st) {
 }
 
 }  // namespace sslcr
+
+namespace sslcr {
+
+// dst[r*ldd + c] (+)= src[r*lds + c], c < w   (concat / tile / slice-sum glue for the fp32 heads)
+__global__ __launch_bounds__(256) void copy2d_kernel(float* dst, long ldd, const float* src, long lds, int rows, int w, int accumulate) {
+  const long total = (long)rows * w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / w, c = i - r * w;
+    const float v = src[r * lds + c];
+    float* d = dst + r * ldd + c;
+    *d = accumulate ? *d + v : v;
+  }
+}
+hipError_t launch_copy2d(float* dst, long ldd, const float* src, long lds, int rows, int w, int accumulate, hipStream_t st) {
+  long b = ((long)rows * w + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(copy2d_kernel, dim3((int)b), dim3(256), 0, st, dst, ldd, src, lds, rows, w, accumulate);
+  return hipGetLastError();
+}
+
+// engine gradient layout [K][RS][C] -> PyTorch [K][C][RS]
+__global__ __launch_bounds__(256) void unpack_grad_kernel(const float* g, float* out, int K, int C, int RS) {
+  const int total = K * C * RS;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int k = i / (C * RS), rem = i - k * C * RS;
+    const int c = rem / RS, rs = rem - c * RS;
+    out[i] = g[(k * RS + rs) * C + c];
+  }
+}
+hipError_t launch_unpack_grad(const float* g, float* out, int K, int C, int RS, hipStream_t st) {
+  int b = cdiv(K * C * RS, 256);
+  if (b > 2048) b = 2048;
+  hipLaunchKernelGGL(unpack_grad_kernel, dim3(b), dim3(256), 0, st, g, out, K, C, RS);
+  return hipGetLastError();
+}
+
+}  // namespace sslcr

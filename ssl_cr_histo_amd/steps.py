@@ -1,0 +1,322 @@
+"""Drop-in ``train()`` / ``validate()`` for the reference scripts, same signatures and return tuples, running every
+iteration as ONE native engine step (teacher fwd + student fwd + losses + backward + all-reduce) plus one fused
+optimizer launch.  Loaders are any iterables yielding the reference's batch tuples, uint8 or float,
+CPU or GPU.  Differences from the reference loops that do not change results: no per-iteration ``.item()`` host syncs
+(meters are filled from device scalars at print/epoch boundaries) and features are concatenated once, not per step.
+
+reference                                   here
+eval_BreastPathQ_SSL_CR.train/validate      bpq_cr_train / bpq_cr_validate      (:37-128 / :131-175)
+eval_Camelyon_SSL_CR.train/validate         cam_cr_train / cam_cr_validate      (:33-157 / :160-225)
+eval_Kather_SSL_CR.train/validate           kather_cr_train / kather_cr_validate(:37-127 / :130-179)
+pretrain_BreastPathQ|Camelyon16|RSP.train   rsp_train / rsp_validate            (:27-92 / :95-148)
+eval_Camelyon_SSL.train                     cam_sup_train                       (:31-119)
+eval_BreastPathQ_SSL.train                  bpq_sup_train                       (:35-103)
+eval_Kather_SSL.train                       kather_sup_train                    (:32-99)
+"""
+import time
+
+import torch
+
+from .engine import get_engine
+from .util import AverageMeter
+
+
+class _Meters:
+    """AverageMeter semantics (util.py:26-46) fed from device scalars without a sync per step."""
+
+    def __init__(self, names):
+        self.names = names
+        self.rows, self.weights = [], []
+
+    def add(self, losses, n):
+        self.rows.append(losses)
+        self.weights.append(n)
+
+    def meters(self, acc_denoms=None):
+        out = {k: AverageMeter() for k in self.names}
+        if not self.rows:
+            return out
+        vals = torch.stack(self.rows).cpu().tolist()              # the single device->host sync
+        for r, n in zip(vals, self.weights):
+            for k in self.names:
+                if k == "acc":
+                    out[k].update(r[3] / n, n)
+                else:
+                    out[k].update(r[{"loss": 0, "loss_x": 1, "loss_u": 2}[k]], n)
+        return out
+
+
+def _device_of(model):
+    return next(model.parameters()).device
+
+
+def _maybe_print(args, batch_idx, tag, epoch, total, t0, meters):
+    pf = getattr(args, "print_freq", 0)
+    if pf and (batch_idx + 1) % pf == 0:
+        m = meters.meters()
+        body = "\t".join(f"{k} {v.val:.3f} ({v.avg:.3f})" for k, v in m.items())
+        print(f"{tag}: [{epoch}][{batch_idx + 1}/{total}]\tBT {(time.time() - t0) / (batch_idx + 1):.3f}\t{body}")
+
+
+def _len(x):
+    try:
+        return len(x)
+    except TypeError:
+        return -1
+
+
+# ------------------------------------------------------------------------------------------------ BreastPathQ SSL_CR
+def bpq_cr_train(args, model_teacher, model_student, classifier_teacher, classifier_student, labeled_train_loader,
+                 unlabeled_train_loader, optimizer, epoch):
+    """eval_BreastPathQ_SSL_CR.train: returns (loss_avg, loss_x_avg, loss_u_avg, final_feats, final_targets)."""
+    eng = get_engine(_device_of(model_student))
+    for m in (model_teacher, classifier_teacher):
+        m.eval()
+    for m in (model_student, classifier_student):
+        m.train()
+    te, st = eng.bind(model_teacher, classifier_teacher), eng.bind(model_student, classifier_student)
+    meters = _Meters(["loss", "loss_x", "loss_u"])
+    feats, targets = [], []
+    t0 = time.time()
+    for batch_idx, (data_x, data_u) in enumerate(zip(labeled_train_loader, unlabeled_train_loader)):
+        inputs_x, targets_x = data_x
+        inputs_u_w, inputs_u_s = data_u
+        inputs_x = inputs_x.reshape(-1, 3, 256, 256)                         # :74 (hard-coded by the reference)
+        targets_x = targets_x.float().to(eng.device)
+        r = eng.step_ssl_cr(te, st, "mse", inputs_x, targets_x.reshape(-1), inputs_u_w, inputs_u_s, args.lambda_u)
+        st.optimizer_step(optimizer)
+        meters.add(r["losses"], inputs_x.shape[0])
+        feats.append(r["feats"])
+        targets.append(targets_x)
+        _maybe_print(args, batch_idx, "Train", epoch, _len(labeled_train_loader), t0, meters)
+    m = meters.meters()
+    return m["loss"].avg, m["loss_x"].avg, m["loss_u"].avg, torch.cat(feats).detach(), torch.cat(targets).detach()
+
+
+def bpq_cr_validate(args, model_student, classifier_student, val_loader, epoch):
+    """eval_BreastPathQ_SSL_CR.validate -> loss_avg."""
+    eng = get_engine(_device_of(model_student))
+    model_student.eval()
+    classifier_student.eval()
+    st = eng.bind(model_student, classifier_student)
+    meters = _Meters(["loss"])
+    t0 = time.time()
+    for batch_idx, (input, target) in enumerate(val_loader):
+        r = eng.step_supervised(st, "mse", [input], target.float().reshape(-1), train=False)
+        meters.add(r["losses"], target.size(0))
+        _maybe_print(args, batch_idx, "Val", epoch, _len(val_loader), t0, meters)
+    return meters.meters()["loss"].avg
+
+
+# ------------------------------------------------------------------------------------------------ Camelyon16 SSL_CR
+def _cat_shuffle(a, b, perm):
+    return torch.cat([a, b])[perm]
+
+
+def cam_cr_train(args, model_teacher, model_student, classifier_teacher, classifier_student, tumor_labeled_train_loader,
+                 normal_labeled_train_loader, tumor_unlabeled_train_loader, normal_unlabeled_train_loader, optimizer, epoch):
+    """eval_Camelyon_SSL_CR.train: returns (loss, loss_x, loss_u, acc, final_feats[:labeled], final_targets)."""
+    eng = get_engine(_device_of(model_student))
+    for m in (model_teacher, classifier_teacher):
+        m.eval()
+    for m in (model_student, classifier_student):
+        m.train()
+    te, st = eng.bind(model_teacher, classifier_teacher), eng.bind(model_student, classifier_student)
+    meters = _Meters(["loss", "loss_x", "loss_u", "acc"])
+    feats, targets = [], []
+    t0 = time.time()
+    S = args.image_size
+    loaders = zip(tumor_labeled_train_loader, normal_labeled_train_loader, tumor_unlabeled_train_loader,
+                  normal_unlabeled_train_loader)
+    for batch_idx, (tumor_data_x, normal_data_x, tumor_data_u, normal_data_u) in enumerate(loaders):
+        t_x, t_y = tumor_data_x
+        n_x, n_y = normal_data_x
+        t_x, t_y = t_x.reshape(-1, 3, S, S), t_y.reshape(-1)
+        n_x, n_y = n_x.reshape(-1, 3, S, S), n_y.reshape(-1)
+        t_uw, t_us = tumor_data_u
+        n_uw, n_us = normal_data_u
+        p_x = torch.randperm(2 * len(t_x))                       # same three draws, same order as :79-81
+        p_uw = torch.randperm(2 * len(t_uw))
+        p_us = torch.randperm(2 * len(t_us))
+        x, y = _cat_shuffle(t_x, n_x, p_x.to(t_x.device)), _cat_shuffle(t_y, n_y, p_x.to(t_y.device)).long()
+        u_w, u_s = _cat_shuffle(t_uw, n_uw, p_uw.to(t_uw.device)), _cat_shuffle(t_us, n_us, p_us.to(t_us.device))
+        r = eng.step_ssl_cr(te, st, "ce", x, y, u_w, u_s, args.lambda_u)
+        st.optimizer_step(optimizer)
+        n = x.shape[0]
+        meters.add(r["losses"], n)
+        feats.append(r["feats"][:n])
+        targets.append(y.to(eng.device))
+        _maybe_print(args, batch_idx, "Train", epoch, _len(tumor_labeled_train_loader) * 2, t0, meters)
+    m = meters.meters()
+    return m["loss"].avg, m["loss_x"].avg, m["loss_u"].avg, m["acc"].avg, torch.cat(feats).detach(), torch.cat(targets).detach()
+
+
+def cam_cr_validate(args, model_student, classifier_student, val_tumor_loader, val_normal_loader, epoch):
+    """eval_Camelyon_SSL_CR.validate -> (loss_avg, acc_avg)."""
+    eng = get_engine(_device_of(model_student))
+    model_student.eval()
+    classifier_student.eval()
+    st = eng.bind(model_student, classifier_student)
+    meters = _Meters(["loss", "acc"])
+    t0 = time.time()
+    for batch_idx, (data_tumor, data_normal) in enumerate(zip(val_tumor_loader, val_normal_loader)):
+        t_x, t_y = data_tumor
+        n_x, n_y = data_normal
+        perm = torch.randperm(2 * len(t_x))
+        x = torch.cat([t_x, n_x])[perm.to(t_x.device)]
+        y = torch.cat([t_y, n_y])[perm.to(t_y.device)].long()
+        r = eng.step_supervised(st, "ce", [x], y, train=False)
+        meters.add(r["losses"], y.size(0))
+        _maybe_print(args, batch_idx, "Val", epoch, 2 * _len(val_tumor_loader), t0, meters)
+    m = meters.meters()
+    return m["loss"].avg, m["acc"].avg
+
+
+# ------------------------------------------------------------------------------------------------ Kather SSL_CR
+def kather_cr_train(args, model_teacher, model_student, classifier_teacher, classifier_student, labeled_train_loader,
+                    unlabeled_train_loader, optimizer, epoch):
+    """eval_Kather_SSL_CR.train: CE + hard-pseudo-label CE, single labeled/unlabeled loader pair;
+    returns (loss, loss_x, loss_u, acc)."""
+    eng = get_engine(_device_of(model_student))
+    for m in (model_teacher, classifier_teacher):
+        m.eval()
+    for m in (model_student, classifier_student):
+        m.train()
+    te, st = eng.bind(model_teacher, classifier_teacher), eng.bind(model_student, classifier_student)
+    meters = _Meters(["loss", "loss_x", "loss_u", "acc"])
+    t0 = time.time()
+    for batch_idx, (data_x, data_u) in enumerate(zip(labeled_train_loader, unlabeled_train_loader)):
+        inputs_x, targets_x = data_x
+        inputs_u_w, inputs_u_s = data_u
+        inputs_x = inputs_x.reshape(-1, 3, 256, 256)                          # :68
+        targets_x = targets_x.reshape(-1).long()                              # :69
+        r = eng.step_ssl_cr(te, st, "ce", inputs_x, targets_x, inputs_u_w, inputs_u_s, args.lambda_u)
+        st.optimizer_step(optimizer)
+        meters.add(r["losses"], inputs_x.shape[0])
+        _maybe_print(args, batch_idx, "Train", epoch, _len(labeled_train_loader), t0, meters)
+    m = meters.meters()
+    return m["loss"].avg, m["loss_x"].avg, m["loss_u"].avg, m["acc"].avg
+
+
+def kather_cr_validate(args, model_student, classifier_student, val_loader, epoch):
+    """eval_Kather_SSL_CR.validate -> (loss_avg, acc_avg)."""
+    eng = get_engine(_device_of(model_student))
+    model_student.eval()
+    classifier_student.eval()
+    st = eng.bind(model_student, classifier_student)
+    meters = _Meters(["loss", "acc"])
+    for batch_idx, (input, target) in enumerate(val_loader):
+        r = eng.step_supervised(st, "ce", [input], target.reshape(-1).long(), train=False)
+        meters.add(r["losses"], target.size(0))
+    m = meters.meters()
+    return m["loss"].avg, m["acc"].avg
+
+
+# ------------------------------------------------------------------------------------------------ RSP pretraining
+def _rsp_epoch(args, model, classifier, loader, criterion, optimizer, epoch, train):
+    if criterion is not None and not isinstance(criterion, torch.nn.CrossEntropyLoss):
+        raise NotImplementedError("the reference trains RSP with nn.CrossEntropyLoss")
+    eng = get_engine(_device_of(model))
+    model.train(train)
+    classifier.train(train)
+    net = eng.bind(model, classifier)
+    meters = _Meters(["loss", "acc"])
+    feats, targets = [], []
+    t0 = time.time()
+    for batch_idx, (input1, input2, input3, target) in enumerate(loader):
+        i1, i2, i3 = (v.reshape(-1, 3, args.tile_h, args.tile_w) for v in (input1, input2, input3))
+        target = target.long().view(-1, 1).reshape(-1)
+        r = eng.step_supervised(net, "ce", [i1, i2, i3], target, train=train)
+        if train:
+            net.optimizer_step(optimizer)
+        meters.add(r["losses"], target.size(0))
+        if train:
+            feats.append(r["feats"])
+            targets.append(target.to(eng.device))
+        _maybe_print(args, batch_idx, "Train" if train else "Val", epoch, _len(loader), t0, meters)
+    m = meters.meters()
+    if train:
+        return m["loss"].avg, m["acc"].avg, torch.cat(feats).detach(), torch.cat(targets).detach()
+    return m["loss"].avg, m["acc"].avg
+
+
+def rsp_train(args, model, classifier, train_loader, criterion, optimizer, epoch):
+    """pretrain_BreastPathQ.train (= pretrain_Camelyon16, Pretraining_v2/pretrain_RSP): (loss, acc, feats, targets)."""
+    return _rsp_epoch(args, model, classifier, train_loader, criterion, optimizer, epoch, True)
+
+
+def rsp_validate(args, model, classifier, val_loader, criterion, epoch):
+    return _rsp_epoch(args, model, classifier, val_loader, criterion, None, epoch, False)
+
+
+# ------------------------------------------------------------------------------------------------ supervised fine-tune
+def cam_sup_train(args, model, classifier, tumor_labeled_train_loader, normal_labeled_train_loader, optimizer, epoch):
+    """eval_Camelyon_SSL.train -> (loss, acc, feats, targets)."""
+    eng = get_engine(_device_of(model))
+    model.train()
+    classifier.train()
+    net = eng.bind(model, classifier)
+    meters = _Meters(["loss", "acc"])
+    feats, targets = [], []
+    S = args.image_size
+    for batch_idx, (tumor_data_x, normal_data_x) in enumerate(zip(tumor_labeled_train_loader, normal_labeled_train_loader)):
+        t_x, t_y = tumor_data_x
+        n_x, n_y = normal_data_x
+        t_x, t_y = t_x.reshape(-1, 3, S, S), t_y.reshape(-1)
+        n_x, n_y = n_x.reshape(-1, 3, S, S), n_y.reshape(-1)
+        perm = torch.randperm(2 * len(t_x))
+        x, y = _cat_shuffle(t_x, n_x, perm.to(t_x.device)), _cat_shuffle(t_y, n_y, perm.to(t_y.device)).long()
+        r = eng.step_supervised(net, "ce", [x], y, train=True)
+        net.optimizer_step(optimizer)
+        meters.add(r["losses"], x.shape[0])
+        feats.append(r["feats"])
+        targets.append(y.to(eng.device))
+    m = meters.meters()
+    return m["loss"].avg, m["acc"].avg, torch.cat(feats).detach(), torch.cat(targets).detach()
+
+
+def bpq_sup_train(args, model, classifier, train_loader, criterion, optimizer, epoch):
+    """eval_BreastPathQ_SSL.train -> (loss, feats, targets)."""
+    if criterion is not None and not isinstance(criterion, torch.nn.MSELoss):
+        raise NotImplementedError("the reference fine-tunes BreastPathQ with nn.MSELoss")
+    eng = get_engine(_device_of(model))
+    model.train()
+    classifier.train()
+    net = eng.bind(model, classifier)
+    meters = _Meters(["loss"])
+    feats, targets = [], []
+    for batch_idx, (input1, target) in enumerate(train_loader):
+        x = input1.reshape(-1, 3, args.image_size, args.image_size)
+        y = target.float().reshape(-1)
+        r = eng.step_supervised(net, "mse", [x], y, train=True)
+        net.optimizer_step(optimizer)
+        meters.add(r["losses"], y.size(0))
+        feats.append(r["feats"])
+        targets.append(y.to(eng.device))
+    m = meters.meters()
+    return m["loss"].avg, torch.cat(feats).detach(), torch.cat(targets).detach()
+
+
+def kather_sup_train(args, model, classifier, train_loader, criterion, optimizer, epoch):
+    """eval_Kather_SSL.train (:32-99; the reference file does not parse, :243): student-only CE -> (loss, acc)."""
+    eng = get_engine(_device_of(model))
+    model.train()
+    classifier.train()
+    net = eng.bind(model, classifier)
+    meters = _Meters(["loss", "acc"])
+    for batch_idx, (input, target) in enumerate(train_loader):
+        x = input.reshape(-1, 3, args.image_size, args.image_size)                   # :57
+        y = target.reshape(-1).long()
+        r = eng.step_supervised(net, "ce", [x], y, train=True)
+        net.optimizer_step(optimizer)
+        meters.add(r["losses"], y.size(0))
+    m = meters.meters()
+    return m["loss"].avg, m["acc"].avg
+
+
+def teacher_refresh(model_teacher, classifier_teacher, model_student, classifier_student, ema_decay=0.0):
+    """In-place form of the reference's per-epoch ``teacher = copy.deepcopy(student)`` (eval_BreastPathQ_SSL_CR.py:515-516),
+    generalised to an EMA (decay 0 == the reference).  ``copy.deepcopy`` itself also works on these modules."""
+    eng = get_engine(_device_of(model_student))
+    te, st = eng.bind(model_teacher, classifier_teacher), eng.bind(model_student, classifier_student)
+    te.ema_from(st, ema_decay)
