@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/s of the ResNet18 SSL_CR (teacher-student consistency) training step on synthetic
+256x256 uint8 patches, bf16 engine mode, one process per GPU.
+
+  python bench.py [--gpus N --steps K --warmup W]                      (N=1 by default)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1, RCCL over xGMI)
+
+A step = one iteration of eval_BreastPathQ_SSL_CR.train() at the per-GPU shapes of BASELINE config 4
+(`--batch_size 512 --mu 7` over 8 GPUs -> b=64/GPU: 192 labeled + 448 strong-unlabeled student images, 448 weak-unlabeled
+teacher images = 1088 distinct patches), full fine-tune (--modules_student 0), MSE+MSE loss, Adam: teacher eval forward,
+student train-mode forward, losses, full backward, gradient all-reduce (N>1), fused Adam update.  Weak scaling: the
+per-GPU batch is fixed.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_FWD = 2 * 2368733184            # backbone forward FLOPs per 256x256 image
+F_BWD_FULL = 2 * F_FWD - 0.308e9  # + dgrad + wgrad, no dgrad for conv1
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="ssl_cr", choices=["ssl_cr", "fwd", "rsp"])
+    ap.add_argument("--batch_size", type=int, default=64, help="per-GPU --batch_size b (ssl_cr: 3b labeled + 7b unlabeled)")
+    ap.add_argument("--mu", type=int, default=7)
+    ap.add_argument("--image_size", type=int, default=256)
+    ap.add_argument("--modules_student", type=int, default=0, help="0 = full fine-tune (headline); 60 = reference default freeze")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def synth_u8(shape, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randint(0, 256, shape, dtype=torch.uint8, generator=g).to(device)
+
+
+def build_nets(args, device, classes=1, triplet=False):
+    from ssl_cr_histo_amd import net
+    torch.manual_seed(42)                                   # the reference's default --seed
+    if triplet:
+        model, cls = net.TripletNet("resnet18"), net.Classifier(768, 6)
+    else:
+        model, cls = net.TripletNet_Finetune("resnet18"), net.FinetuneResNet(classes)
+    return model.to(device), cls.to(device)
+
+
+def cpu_baseline(args):
+    """oracle (CPU restatement of the reference step, torch CPU fp32) timed on this box's host cores, bounded sample."""
+    from collections import OrderedDict
+    from oracle import model as OM, steps as S
+    # torch-CPU convolutions on a 17-image batch stop scaling (and collapse) far below a 256-thread host: use 32 threads
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    hw, b, mu = args.image_size, 1, args.mu
+    nx, nu = 3 * b, mu * b
+    sd = OM.init_state(42, OM.net_param_specs())
+    csd = OM.init_state(43, OM.classifier_param_specs("finetune", 1))
+    def mk():
+        p, bufs = OM.split_state(OrderedDict((k, v.clone()) for k, v in sd.items()))
+        pc, _ = OM.split_state(OrderedDict((k, v.clone()) for k, v in csd.items()))
+        p.update(pc)
+        return p, bufs
+    ps, bs = mk()
+    pt, bt = mk()
+    for i, v in enumerate(ps.values()):
+        v.requires_grad_(i >= args.modules_student)
+    opt = S.Adam(ps.values(), 1e-4, (0.9, 0.999), 1e-8, 1e-4)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randint(0, 256, (nx, 3, hw, hw), generator=g).float()
+    u_w = torch.randint(0, 256, (nu, 3, hw, hw), generator=g).float()
+    u_s = torch.randint(0, 256, (nu, 3, hw, hw), generator=g).float()
+    y = torch.rand(nx, generator=g)
+    times = []
+    budget_t0 = time.time()
+    for it in range(3):
+        t0 = time.time()
+        S.ssl_cr_step("mse", ps, bs, pt, bt, opt, x, y, u_w, u_s, 1.0, faithful=True)
+        times.append(time.time() - t0)
+        if it >= 1 and time.time() - budget_t0 > 30.0:       # bounded: ~10-30 s of CPU work
+            break
+    t = min(times[1:]) if len(times) > 1 else times[0]
+    patches = nx + 2 * nu
+    return {"value": round(patches / t, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"oracle ssl_cr_step (faithful: 3 backbone passes per image like models/net.py:88-90), b={b} mu={mu} "
+                      f"-> {nx} labeled + {nu}+{nu} unlabeled {hw}x{hw} patches, modules_student={args.modules_student}, "
+                      f"fp32 torch-CPU, {threads} threads of {os.cpu_count()} host cores, best of {max(1, len(times) - 1)} timed "
+                      f"step(s) after 1 warm-up ({t:.2f} s/step)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import torch.distributed as dist
+    from ssl_cr_histo_amd import dist as sdist
+    from ssl_cr_histo_amd import engine as E
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+    eng = E.set_engine(E.Engine(device, args.dtype))
+    sdist.attach_engine(eng)
+
+    hw, b, mu = args.image_size, args.batch_size, args.mu
+    lr, wd = 1e-4, 1e-4
+    if args.workload == "ssl_cr":
+        nx, nu = 3 * b, mu * b
+        mt, ct = build_nets(args, device)
+        ms, cs = build_nets(args, device)
+        for m in (mt, ct):
+            m.eval()
+        for m in (ms, cs):
+            m.train()
+        for p in list(mt.parameters()) + list(ct.parameters()):
+            p.requires_grad = False
+        for i, (_, p) in enumerate(ms.named_parameters()):
+            p.requires_grad = i >= args.modules_student
+        te, st = eng.bind(mt, ct), eng.bind(ms, cs)
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())), lr=lr,
+                               betas=(0.9, 0.999), weight_decay=wd)
+        x = synth_u8((nx, 3, hw, hw), 1234 + rank, device)
+        u_w = synth_u8((nu, 3, hw, hw), 2234 + rank, device)
+        u_s = synth_u8((nu, 3, hw, hw), 3234 + rank, device)
+        y = torch.rand(nx, generator=torch.Generator().manual_seed(4234 + rank)).to(device)
+        patches = nx + 2 * nu
+
+        def step():
+            r = eng.step_ssl_cr(te, st, "mse", x, y, u_w, u_s, 1.0)
+            st.optimizer_step(opt)
+            return r
+        bwd = args.modules_student < 60
+        flops_step = nu * F_FWD + (nx + nu) * (F_FWD + (F_BWD_FULL if args.modules_student == 0 else 0))
+        cfg = {"workload": f"eval_BreastPathQ_SSL_CR.train step, per-GPU --batch_size {b} --mu {mu}: student {nx}+{nu}, teacher {nu} "
+                           f"({patches} distinct {hw}x{hw} uint8 patches/step/GPU), modules_student={args.modules_student}, Adam",
+               "global_batch_patches": patches * world, "parallelism": f"dp{world}", "backward": bwd}
+    elif args.workload == "fwd":
+        n = 4 * b
+        ms, cs = build_nets(args, device)
+        ms.eval()
+        st = eng.bind(ms, cs)
+        x = synth_u8((n, 3, hw, hw), 1234 + rank, device)
+        patches = n
+
+        def step():
+            return st.forward((x,), train=False)
+        flops_step = n * F_FWD
+        cfg = {"workload": f"ResNet18 TripletNet_Finetune forward-only (eval BN folded), N={n} {hw}x{hw}", "parallelism": f"dp{world}"}
+    else:
+        B = 2 * b
+        ms, cs = build_nets(args, device, triplet=True)
+        ms.train()
+        st = eng.bind(ms, cs)
+        opt = torch.optim.SGD(list(ms.parameters()) + list(cs.parameters()), lr=0.01, momentum=0.9, weight_decay=wd, nesterov=True)
+        xs = [synth_u8((B, 3, hw, hw), 1234 + 10 * i + rank, device) for i in range(3)]
+        y = torch.randint(0, 6, (B,), generator=torch.Generator().manual_seed(5234 + rank)).to(device)
+        patches = 3 * B
+
+        def step():
+            r = eng.step_supervised(st, "ce", xs, y, train=True)
+            st.optimizer_step(opt)
+            return r
+        flops_step = 3 * B * (F_FWD + F_BWD_FULL)
+        cfg = {"workload": f"pretrain_BreastPathQ.train step (RSP), B={B} triplets {hw}x{hw}, SGD-Nesterov", "parallelism": f"dp{world}"}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = patches * world * args.steps / dt
+
+    out = {"metric": "images/sec (ResNet18 SSL_CR step, 256x256 bf16 synthetic patches; whole job)" if args.workload == "ssl_cr"
+           else f"images/sec ({args.workload})",
+           "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic", "config": cfg,
+           "per_gpu_images_per_s": round(value / world, 1),
+           "achieved_tflops_per_gpu_algorithmic": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2)}
+
+    if rank == 0 and not args.no_roofline:
+        # roofline leg: same steps again with every conv launch bracketed by HIP events on its own stream
+        eng.profile(True)
+        for _ in range(max(2, min(5, args.steps))):
+            step()
+        torch.cuda.synchronize()
+        pr = [eng.profile_read(0), eng.profile_read(1)]
+        eng.profile(False)
+        names = ["conv_igemm_kernel (forward + dgrad)", "wgrad_kernel"]
+        dom = 0 if pr[0]["ms"] >= pr[1]["ms"] else 1
+        peak = 2500.0 if args.dtype == "bf16" else 157.3
+        if pr[dom]["launches"]:
+            ach = pr[dom]["flops"] / (pr[dom]["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(ach / peak, 4), "traffic": None,
+                               "launches": pr[dom]["launches"], "avg_launch_us": round(pr[dom]["ms"] * 1e3 / pr[dom]["launches"], 2),
+                               "algorithmic_gflop_per_launch": round(pr[dom]["flops"] / pr[dom]["launches"] / 1e9, 3),
+                               "algorithmic_gb_s": round(pr[dom]["bytes"] / (pr[dom]["ms"] * 1e-3) / 1e9, 1)}
+            oth = 1 - dom
+            if pr[oth]["launches"]:
+                out["roofline_other"] = {"kernel": names[oth], "achieved": round(pr[oth]["flops"] / (pr[oth]["ms"] * 1e-3) / 1e12, 2),
+                                         "unit": "TFLOP/s", "launches": pr[oth]["launches"], "ms": round(pr[oth]["ms"], 3)}
+            out["conv_time_share"] = round((pr[0]["ms"] + pr[1]["ms"]) / (ms_per_step * max(2, min(5, args.steps))), 3)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "ssl_cr":
+        out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,12 @@ int sslcr_destroy(sslcr_ctx* ctx);
 int sslcr_comm_unique_id(void* id128);
 int sslcr_comm_init(sslcr_ctx* ctx, const void* id128, int rank, int world);
 
+/* measurement: bracket every conv launch of this ctx with HIP events on its own stream (bench.py roofline leg).
+ * which = 0: conv_igemm (forward + dgrad), 1: wgrad.  out4 = {launches, total ms, algorithmic FLOPs, algorithmic bytes}.
+ * sslcr_profile(ctx, 1) also clears the previous records. */
+int sslcr_profile(sslcr_ctx* ctx, int enable);
+int sslcr_profile_read(sslcr_ctx* ctx, int which, double* out4);
+
 typedef struct sslcr_net_desc {
   float* const* params;                    /* [nparams] device pointers, named_parameters() order of models/net.py:
                                               0..59 resnet18 backbone, 60..63 fc.0/fc.2, then the classifier (2 or 4) */

@@ -94,7 +94,24 @@ struct PassState {
 
 }  // namespace
 
+struct ProfRec {
+  hipEvent_t e0, e1;
+  double flops, bytes;
+};
+struct Profiler {               // optional HIP-event bracketing of the conv launches (bench.py roofline leg)
+  bool on = false;
+  std::vector<ProfRec> rec[2];  // 0: conv_igemm (fwd + dgrad), 1: wgrad
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+};
+
 struct sslcr_ctx {
+  Profiler prof;
   int device = 0, dtype = 0;
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
@@ -138,7 +155,40 @@ struct sslcr_net {
 
 namespace {
 
-const int kBlockCfg[8][3] = {{64, 64, 1}, {64, 64, 1}, {64, 128, 2}, {128, 128, 1}, {128, 256, 2}, {256, 256, 1}, {256, 512, 2}, {512, 512, 1}};
+// ---- launch wrappers: when profiling is on, bracket the kernel with HIP events on ITS stream and book the
+// algorithmic work (forward-conv FLOPs even for the strided dgrad gather, whose zero taps are not counted)
+hipError_t prof_conv(sslcr_ctx* c, int dt, const ConvArgs& a, hipStream_t st) {
+  if (!c->prof.on) return launch_conv(dt, a, st);
+  ProfRec r;
+  r.e0 = c->prof.get(); r.e1 = c->prof.get();
+  const double es = c->esz();
+  const double rs = (double)a.R * a.S;
+  const double M = (double)a.N * a.PH * a.PW;
+  const double src = (double)a.N * a.H * a.W;
+  r.flops = a.transposed ? 2.0 * src * a.C * a.K * rs : 2.0 * M * a.K * a.C * rs;
+  r.bytes = (src * a.C + (double)a.K * rs * a.C + M * a.K * (a.residual ? 2.0 : 1.0) * (a.accumulate ? 2.0 : 1.0)) * es;
+  (void)hipEventRecord(r.e0, st);
+  hipError_t e = launch_conv(dt, a, st);
+  (void)hipEventRecord(r.e1, st);
+  c->prof.rec[0].push_back(r);
+  return e;
+}
+hipError_t prof_wgrad(sslcr_ctx* c, int dt, const WgradArgs& a, hipStream_t st) {
+  if (!c->prof.on) return launch_wgrad(dt, a, st);
+  ProfRec r;
+  r.e0 = c->prof.get(); r.e1 = c->prof.get();
+  const double es = c->esz();
+  const double M = (double)a.N * a.OH * a.OW;
+  r.flops = 2.0 * M * a.K * a.C * a.R * a.S;
+  r.bytes = ((double)a.N * a.H * a.W * a.C + M * a.K) * es + (double)a.K * a.R * a.S * a.C * 4.0;
+  (void)hipEventRecord(r.e0, st);
+  hipError_t e = launch_wgrad(dt, a, st);
+  (void)hipEventRecord(r.e1, st);
+  c->prof.rec[1].push_back(r);
+  return e;
+}
+
+const int kBlockCfg[8][3] ={{64, 64, 1}, {64, 64, 1}, {64, 128, 2}, {128, 128, 1}, {128, 256, 2}, {256, 256, 1}, {256, 512, 2}, {512, 512, 1}};
 
 inline int out_dim(int h, int k, int stride, int pad) { return (h + 2 * pad - k) / stride + 1; }
 
@@ -377,13 +427,13 @@ int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f3
     ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fwd, ps.blk[i].raw1, N, xh, xw);
     TRYI(ensure_partials(c, a1, &part, &rows));
     a1.stats = part;
-    TRY(launch_conv(dt, a1, st));
+    TRY(prof_conv(c, dt,a1, st));
     TRYI(finalize_bn(n, B.b1, part, rows, (double)N * oh * ow, ps.bn[B.b1.bidx], replay, st));
     ConvArgs a2 = conv_args(B.c2, ps.blk[i].raw1, B.c2.w_fwd, ps.blk[i].raw2, N, oh, ow);
     a2.in_scale = ps.bn[B.b1.bidx].scale; a2.in_shift = ps.bn[B.b1.bidx].shift; a2.in_relu = 1;
     TRYI(ensure_partials(c, a2, &part, &rows));
     a2.stats = part;
-    TRY(launch_conv(dt, a2, st));
+    TRY(prof_conv(c, dt,a2, st));
     TRYI(finalize_bn(n, B.b2, part, rows, (double)N * oh * ow, ps.bn[B.b2.bidx], replay, st));
     BnActArgs e;
     memset(&e, 0, sizeof(e));
@@ -393,7 +443,7 @@ int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f3
       ConvArgs ad = conv_args(B.ds, X, B.ds.w_fwd, ps.blk[i].rawd, N, xh, xw);
       TRYI(ensure_partials(c, ad, &part, &rows));
       ad.stats = part;
-      TRY(launch_conv(dt, ad, st));
+      TRY(prof_conv(c, dt,ad, st));
       TRYI(finalize_bn(n, B.bd, part, rows, (double)N * oh * ow, ps.bn[B.bd.bidx], replay, st));
       e.res = ps.blk[i].rawd; e.rscale = ps.bn[B.bd.bidx].scale; e.rshift = ps.bn[B.bd.bidx].shift;
     } else {
@@ -441,17 +491,17 @@ int backbone_forward_eval(sslcr_net* n, const void* x, int in_f32, int N, int H,
     const int oh = d.lh[i], ow = d.lw[i];
     ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fold, t1, N, xh, xw);
     a1.bias = B.c1.b_fold; a1.relu = 1;
-    TRY(launch_conv(dt, a1, st));
+    TRY(prof_conv(c, dt,a1, st));
     const void* res = X;
     if (B.has_ds) {
       ConvArgs ad = conv_args(B.ds, X, B.ds.w_fold, td, N, xh, xw);
       ad.bias = B.ds.b_fold;
-      TRY(launch_conv(dt, ad, st));
+      TRY(prof_conv(c, dt,ad, st));
       res = td;
     }
     ConvArgs a2 = conv_args(B.c2, t1, B.c2.w_fold, Y, N, oh, ow);
     a2.bias = B.c2.b_fold; a2.residual = res; a2.relu = 1;
-    TRY(launch_conv(dt, a2, st));
+    TRY(prof_conv(c, dt,a2, st));
     xi = (xi + 3) & 3; xh = oh; xw = ow;
   }
   TRY(launch_avgpool_fwd(dt, base + o_buf[xi], E, N, xh * xw, 512, st));
@@ -575,7 +625,7 @@ int wgrad_call(sslcr_net* n, const ConvL& L, const void* x, const void* dy, cons
   a.x = x; a.dy = dy; a.dw = (float*)n->grads.p + n->goff[L.pidx];
   if (pro) { a.in_scale = pro->scale; a.in_shift = pro->shift; a.in_relu = 1; }
   a.N = N; a.H = H; a.W = W; a.C = L.cin; a.K = L.cout; a.R = L.k; a.S = L.k; a.stride = L.stride; a.pad = L.pad; a.OH = OH; a.OW = OW;
-  TRY(launch_wgrad(n->ctx->dtype, a, st));
+  TRY(prof_wgrad(n->ctx, n->ctx->dtype, a, st));
   return 0;
 }
 
@@ -634,7 +684,7 @@ int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pa
     {
       ConvArgs a = conv_args(B.c2, dRaw2, B.c2.w_dg, dAct1, N, oh, ow);      // dgrad 3x3/1: gather over dRaw2 [.,K] with [C][R][S][K]
       a.C = B.c2.cout; a.K = B.c2.cin; a.transposed = 1; a.PH = oh; a.PW = ow; a.OH = oh; a.OW = ow;
-      TRY(launch_conv(dt, a, st));
+      TRY(prof_conv(c, dt,a, st));
     }
     TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, 1, dRaw1, nullptr, opix, (double)opix, st));
     TRYI(wgrad_call(n, B.c1, X, dRaw1, nullptr, N, xh, xw, oh, ow, st));
@@ -643,12 +693,12 @@ int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pa
       ConvArgs a = conv_args(B.c1, dRaw1, B.c1.w_dg, dXin, N, oh, ow);
       a.C = B.c1.cout; a.K = B.c1.cin; a.transposed = 1; a.PH = xh; a.PW = xw; a.OH = xh; a.OW = xw;
       if (!B.has_ds) a.residual = G;
-      TRY(launch_conv(dt, a, st));
+      TRY(prof_conv(c, dt,a, st));
       if (B.has_ds) {       // 1x1/2 projection: scatter-accumulate into the even positions of dXin
         ConvArgs s = conv_args(B.ds, dRawD, B.ds.w_dg, dXin, N, oh, ow);
         s.C = B.ds.cout; s.K = B.ds.cin; s.stride = 1; s.pad = 0; s.PH = oh; s.PW = ow; s.OH = xh; s.OW = xw; s.osh = B.ds.stride;
         s.accumulate = 1;
-        TRY(launch_conv(dt, s, st));
+        TRY(prof_conv(c, dt,s, st));
       }
       char* t = dOut; dOut = dXin; dXin = t;        // ping-pong: this block's input gradient is the next dOut
     }
@@ -757,6 +807,31 @@ int sslcr_destroy(sslcr_ctx* c) {
   }
   c->scratch.release(); c->partials.release(); c->small.release();
   delete c;
+  return 0;
+}
+
+int sslcr_profile(sslcr_ctx* c, int enable) {
+  if (!c) return fail("sslcr_profile: null");
+  c->prof.on = enable != 0;
+  if (enable) {
+    for (int w = 0; w < 2; ++w) {
+      for (auto& r : c->prof.rec[w]) { c->prof.pool.push_back(r.e0); c->prof.pool.push_back(r.e1); }
+      c->prof.rec[w].clear();
+    }
+  }
+  return 0;
+}
+
+int sslcr_profile_read(sslcr_ctx* c, int which, double* out4) {
+  if (!c || !out4 || which < 0 || which > 1) return fail("sslcr_profile_read: invalid argument");
+  TRY(hipDeviceSynchronize());
+  double ms = 0.0, fl = 0.0, by = 0.0;
+  for (auto& r : c->prof.rec[which]) {
+    float t = 0.f;
+    TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+    ms += t; fl += r.flops; by += r.bytes;
+  }
+  out4[0] = (double)c->prof.rec[which].size(); out4[1] = ms; out4[2] = fl; out4[3] = by;
   return 0;
 }
 

@@ -30,6 +30,8 @@ SupDesc = type("SupDesc", (C.Structure,), {"_fields_": [
 _ENGINE_SIGS = {
     "sslcr_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "sslcr_destroy": (C.c_int, [C.c_void_p]),
+    "sslcr_profile": (C.c_int, [C.c_void_p, C.c_int]),
+    "sslcr_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "sslcr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "sslcr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "sslcr_net_create": (C.c_int, [C.c_void_p, C.POINTER(SslcrNetDesc), C.POINTER(C.c_void_p)]),
@@ -252,6 +254,16 @@ class Engine:
         idbuf = (C.c_char * 128).from_buffer_copy(raw)
         L.check(L.lib().sslcr_comm_init(self.handle, idbuf, rank, world))
         self.rank, self.world = rank, world
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, enable):
+        L.check(L.lib().sslcr_profile(self.handle, int(enable)))
+
+    def profile_read(self, which):
+        """{launches, ms, flops, bytes} of the event-bracketed conv launches (0 conv_igemm fwd+dgrad, 1 wgrad)."""
+        out = (C.c_double * 4)()
+        L.check(L.lib().sslcr_profile_read(self.handle, which, out))
+        return dict(launches=int(out[0]), ms=out[1], flops=out[2], bytes=out[3])
 
     # ------------------------------------------------------------------ binding
     def as_input(self, x):
