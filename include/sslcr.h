@@ -163,6 +163,7 @@ typedef struct sslcr_pack_desc {
   const float* w; void* w_fwd; void* w_dgrad;
   const float* gamma; const float* beta; const float* rmean; const float* rvar; float eps; float* bias_out;
   int K, C, R, S;
+  int dgrad_flip;         /* w_dgrad taps reversed ([C][R-1-r][S-1-s][K]): a stride-1 dgrad then IS a plain conv of dY */
 } sslcr_pack_desc;
 int sslcr_pack_conv(int dtype, const sslcr_pack_desc* d, void* stream);
 int sslcr_pack_stem(int dtype, const sslcr_pack_desc* d, void* stream);

@@ -54,7 +54,7 @@ TensorDesc = _S("TensorDesc", [("p", vp), ("g", vp), ("s1", vp), ("s2", vp), ("n
 OptDesc = _S("OptDesc", [("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("wd", f32),
                          ("momentum", f32), ("bc1", f32), ("bc2", f32), ("first_step", i32), ("grad_scale", f32)])
 PackDesc = _S("PackDesc", [("w", vp), ("w_fwd", vp), ("w_dgrad", vp), ("gamma", vp), ("beta", vp), ("rmean", vp),
-                           ("rvar", vp), ("eps", f32), ("bias_out", vp)] + [(k, i32) for k in ("K", "C", "R", "S")])
+                           ("rvar", vp), ("eps", f32), ("bias_out", vp)] + [(k, i32) for k in ("K", "C", "R", "S", "dgrad_flip")])
 
 # symbol -> (restype, argtypes); every symbol include/sslcr.h declares
 P = C.POINTER

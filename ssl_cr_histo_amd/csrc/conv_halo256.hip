@@ -1,0 +1,287 @@
+// 3x3 / stride 1 / pad 1 NHWC convolution, 256-pixel LDS-halo form: the main MFMA kernel of the engine
+// (ResNet18 layer1-4 block convs forward, and their dgrads through tap-flipped [C][R][S][K] packs).
+//
+// Why this shape.  At 2048 MAC/clk/CU the operand paths are the limit, not the matrix pipe: global->LDS moves 64 B/clk,
+// LDS writes ~80 B/clk, LDS reads 256 B/clk.  A workgroup computing P pixels x Kb kouts needs 2/P bytes of weights and
+// ~2*1.3/(9*Kb) bytes of activations per MAC, so the tile is made big in P: 512 threads (8 waves, 2 per SIMD) own a
+// 16x16-pixel (or 4 images x 8x8) x BKO-kout tile.  Per 128-byte channel slab the 18x18 input halo is staged in LDS once
+// (producer BatchNorm+ReLU applied on the way; zero padding stays zero) and serves all nine taps at shifted offsets; the
+// weights stream through a double-buffered LDS ring one tap (BKO x 128 B) at a time: 16 B/clk of global->LDS traffic per
+// CU instead of 64.  Fragment reads are XOR-swizzled ds_read_b128; epilogue conventions are those of conv_igemm.hip.
+#include "kernels.hpp"
+
+namespace sslcr {
+
+template <typename T> struct MmaQ;
+template <> struct MmaQ<bf16_t> {
+  __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct MmaQ<float> {
+  __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+template <typename T, int TW, int BKO>
+__global__ __launch_bounds__(512, 2) void conv3x3_halo256_kernel(const ConvArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int CE = 8 * EPC;
+  constexpr int TH = TW;                      // 16x16 tile of one image, or 8x8 tiles of four images
+  constexpr int NI = 256 / (TH * TW);
+  constexpr int HH = TH + 2, HWD = TW + 2;
+  constexpr int HP = NI * HH * HWD;           // 324 or 400 halo pixels
+  constexpr int NLD = (HP * 8 + 511) / 512;   // 16-byte halo staging loads per thread
+  constexpr int WLD = BKO * 8 / 512;          // 16-byte weight staging loads per thread per tap (1 or 2)
+  constexpr int TK = BKO / 32, TP = 4;
+  constexpr int HBUF = HP * 128, WBUF = BKO * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_halo = smem;
+  char* s_w = smem + HBUF;                    // [2][BKO][128 B]
+  float* s_scale = reinterpret_cast<float*>(smem + HBUF + 2 * WBUF);
+  float* s_shift = s_scale + a.C;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, li = lane & 15;
+  const int wp = wave & 3, wk = wave >> 2;
+  const int tiles_w = a.W / TW, tiles_h = a.H / TH;
+  int tile = blockIdx.x;
+  const int tw_i = tile % tiles_w; tile /= tiles_w;
+  const int th_i = tile % tiles_h;
+  const int n0 = (tile / tiles_h) * NI;
+  const int h0 = th_i * TH, w0 = tw_i * TW;
+  const int k0 = blockIdx.y * BKO;
+  const bool xform = a.in_scale != nullptr;
+  if (xform)
+    for (int c = tid; c < a.C; c += 512) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
+
+  const int chunk = tid & 7;
+  int src_off[NLD], dst_off[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int hp = (tid >> 3) + 64 * i;
+    if (hp < HP) {
+      const int ni = hp / (HH * HWD), rem = hp - ni * (HH * HWD);
+      const int hr = rem / HWD, hc = rem - hr * HWD;
+      const int h = h0 - 1 + hr, w = w0 - 1 + hc;
+      src_off[i] = (h >= 0 && w >= 0 && h < a.H && w < a.W) ? ((n0 + ni) * a.H + h) * a.W + w : -1;
+      dst_off[i] = hp * 128 + ((chunk ^ (hp & 7)) << 4);
+    } else {
+      src_off[i] = -2; dst_off[i] = 0;
+    }
+  }
+  const char* xg = reinterpret_cast<const char*>(a.x);
+  const char* wg = reinterpret_cast<const char*>(a.w);
+  const int nslabs = a.C / CE;
+
+  u32x4_t hreg[NLD], wreg[WLD];
+  auto load_halo = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (src_off[i] >= 0) v = ld16(xg + ((size_t)src_off[i] * a.C + slab * CE + chunk * EPC) * sizeof(T));
+      hreg[i] = v;
+    }
+  };
+  auto store_halo = [&](int slab) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      if (src_off[i] == -2) continue;
+      u32x4_t v = hreg[i];
+      if (xform && src_off[i] >= 0) {
+        float f[EPC];
+        Elem<T>::unpack(v, f);
+        const int cb = slab * CE + chunk * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float t = fmaf(f[e], s_scale[cb + e], s_shift[cb + e]);
+          f[e] = a.in_relu ? fmaxf(t, 0.f) : t;
+        }
+        v = Elem<T>::pack(f);
+      }
+      st16(s_halo + dst_off[i], v);
+    }
+  };
+  // weights of one (slab, tap): rows k0 .. k0+BKO-1, 128 B each; thread -> (row = tid>>3 (+64), chunk)
+  auto load_w = [&](int slab, int tap) {
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+      const int row = (tid >> 3) + 64 * i;
+      wreg[i] = ld16(wg + (((size_t)(k0 + row) * 9 + tap) * a.C + slab * CE + chunk * EPC) * sizeof(T));
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+      const int row = (tid >> 3) + 64 * i;
+      if (row < BKO) st16(s_w + buf * WBUF + row * 128 + ((chunk ^ (row & 7)) << 4), wreg[i]);
+    }
+  };
+
+  int hbase[TP];
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int pg = wp * 4 + p;                 // 16-pixel group 0..15 of the tile
+    if (TW == 16) {
+      hbase[p] = pg * HWD + li;
+    } else {
+      hbase[p] = (pg >> 2) * (HH * HWD) + (2 * (pg & 3) + (li >> 3)) * HWD + (li & 7);
+    }
+  }
+  int arow[TK];
+#pragma unroll
+  for (int t = 0; t < TK; ++t) arow[t] = wk * (BKO / 2) + (li >> 2) * (4 * TK) + t * 4 + (li & 3);
+
+  f32x4_t acc[TK][TP];
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int p = 0; p < TP; ++p) acc[t][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  if (xform) __syncthreads();
+  load_halo(0);
+  if (BKO * 8 >= 512 || tid < BKO * 8) load_w(0, 0);
+  store_halo(0);
+  store_w(0);
+  __syncthreads();
+
+  int wb = 0;
+  for (int slab = 0; slab < nslabs; ++slab) {
+    const bool more = slab + 1 < nslabs;
+    if (more) load_halo(slab + 1);            // in flight during the nine taps of this slab
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const bool wnext = tap < 8 || more;
+      if (wnext) {
+        if (tap < 8) load_w(slab, tap + 1); else load_w(slab + 1, 0);
+      }
+      const int r = tap / 3, s = tap - 3 * r;
+      const int toff = r * HWD + s;
+      const char* wbuf = s_w + wb * WBUF;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int ci = kk * 4 + g;
+        u32x4_t af[TK], bfr[TP];
+#pragma unroll
+        for (int t = 0; t < TK; ++t) af[t] = ld16(wbuf + arow[t] * 128 + ((ci ^ (arow[t] & 7)) << 4));
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+          const int hp = hbase[p] + toff;
+          bfr[p] = ld16(s_halo + hp * 128 + ((ci ^ (hp & 7)) << 4));
+        }
+#pragma unroll
+        for (int t = 0; t < TK; ++t)
+#pragma unroll
+          for (int p = 0; p < TP; ++p) MmaQ<T>::run(af[t], bfr[p], acc[t][p]);
+      }
+      if (tap == 8 && more) {
+        __syncthreads();                      // every wave is done with this slab's halo
+        store_halo(slab + 1);
+      }
+      if (wnext) store_w(wb ^ 1);
+      __syncthreads();
+      wb ^= 1;
+    }
+  }
+
+  // ---------------- epilogue
+  const int kb = k0 + wk * (BKO / 2) + g * (4 * TK);
+  float bias[4 * TK];
+#pragma unroll
+  for (int j = 0; j < 4 * TK; ++j) bias[j] = a.bias ? a.bias[kb + j] : 0.f;
+  char* yg = reinterpret_cast<char*>(a.y);
+  const char* rg = reinterpret_cast<const char*>(a.residual);
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int pg = wp * 4 + p;
+    int n, h, w;
+    if (TW == 16) { n = n0; h = h0 + pg; w = w0 + li; }
+    else { n = n0 + (pg >> 2); h = h0 + 2 * (pg & 3) + (li >> 3); w = w0 + (li & 7); }
+    const size_t off = ((((size_t)n * a.H + h) * a.W + w) * a.K + kb) * sizeof(T);
+    float v[4 * TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[t * 4 + j] = acc[t][p][j] + bias[t * 4 + j];
+#pragma unroll
+    for (int q = 0; q < 4 * TK / EPC; ++q) {
+      float* vq = v + q * EPC;
+      if (rg) {
+        float rr[EPC];
+        Elem<T>::unpack(ld16(rg + off + q * 16), rr);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) vq[e] = fmaxf(vq[e], 0.f);
+      }
+      st16(yg + off + q * 16, Elem<T>::pack(vq));
+    }
+  }
+  if (a.stats) {
+    float s1[4 * TK], s2[4 * TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < TP; ++p) { float q = acc[t][p][j]; x1 += q; x2 = fmaf(q, q, x2); }
+        s1[t * 4 + j] = row16_sum(x1);
+        s2[t * 4 + j] = row16_sum(x2);
+      }
+    if (li == 0) {
+      float* sp = a.stats + ((size_t)(blockIdx.x * 4 + wp) * 2) * a.K + kb;
+#pragma unroll
+      for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
+    }
+  }
+}
+
+// 0: not applicable; 16: 16x16 tiles; 8: four images x 8x8
+int conv_halo256_mode(int dtype, const ConvArgs& a) {
+  if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.transposed || a.accumulate || a.osh != 1) return 0;
+  if (a.PH != a.H || a.PW != a.W || a.OH != a.H || a.OW != a.W) return 0;
+  const int ce = dtype == DT_BF16 ? 64 : 32;
+  if (a.C % ce != 0 || a.K % 64 != 0) return 0;
+  if (a.H % 16 == 0 && a.W % 16 == 0) return 16;
+  if (a.H == 8 && a.W == 8 && a.N % 4 == 0) return 8;
+  return 0;
+}
+
+int conv_halo256_tiles(const ConvArgs& a, int mode) {
+  return mode == 16 ? a.N * (a.H / 16) * (a.W / 16) : a.N / 4;
+}
+
+template <typename T, int TW, int BKO>
+static hipError_t launch_q(const ConvArgs& a, hipStream_t st) {
+  constexpr int HP = (256 / (TW * TW)) * (TW + 2) * (TW + 2);
+  const size_t lds = HP * 128 + 2 * BKO * 128 + 2 * a.C * sizeof(float);
+  auto kern = conv3x3_halo256_kernel<T, TW, BKO>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  dim3 grid(conv_halo256_tiles(a, TW), a.K / BKO);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_qt(const ConvArgs& a, int mode, hipStream_t st) {
+  const bool wide = a.K % 128 == 0;
+  if (mode == 16) return wide ? launch_q<T, 16, 128>(a, st) : launch_q<T, 16, 64>(a, st);
+  return wide ? launch_q<T, 8, 128>(a, st) : launch_q<T, 8, 64>(a, st);
+}
+
+hipError_t launch_conv_halo256(int dtype, const ConvArgs& a, int mode, hipStream_t st) {
+  return dtype == DT_BF16 ? launch_qt<bf16_t>(a, mode, st) : launch_qt<float>(a, mode, st);
+}
+
+}  // namespace sslcr

@@ -261,7 +261,12 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+static int g_conv_dtype_hint = DT_BF16;   // conv_partials_rows() is asked before the launch: both dtypes tile identically
 int conv_partials_rows(const ConvArgs& a) {
+  const int q = conv_halo256_mode(g_conv_dtype_hint, a);
+  if (q) return conv_halo256_tiles(a, q) * 4;
+  const int tw = conv_halo_tw(g_conv_dtype_hint, a);
+  if (tw) return conv_halo_tiles(a, tw) * 2;
   const int M = a.N * a.PH * a.PW;
   return cdiv(M, conv_tile_bp(a)) * 2;
 }
@@ -284,6 +289,10 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
+  const int q = conv_halo256_mode(dtype, a);
+  if (q && conv_halo256_mode(DT_BF16, a) == q) return launch_conv_halo256(dtype, a, q, st);
+  const int tw = q ? 0 : conv_halo_tw(dtype, a);
+  if (tw && conv_halo_tw(DT_BF16, a) == tw) return launch_conv_halo(dtype, a, tw, st);   // (same tiling in both dtypes)
   return dtype == DT_BF16 ? launch_t<bf16_t>(a, st) : launch_t<float>(a, st);
 }
 

@@ -29,7 +29,7 @@ template <> struct WgFrag<bf16_t> {
 };
 
 template <typename T, int TAPS>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int steps_per_split) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int steps_per_split) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int PS = BF ? 32 : 16;             // pixels per step
@@ -38,8 +38,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int steps
   constexpr int TILE = PS * RB;                // 4 KiB
   constexpr int BUF = (1 + TAPS) * TILE;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* s_scale = reinterpret_cast<float*>(smem + 2 * BUF);
-  float* s_shift = s_scale + 64;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -48,7 +46,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int steps
   const int M = a.N * OHW;
   const int row = tid / CPR, chunk = tid % CPR;
   const bool xform = a.in_scale != nullptr;
-  if (xform && tid < 64) { s_scale[tid] = a.in_scale[c0 + tid]; s_shift[tid] = a.in_shift[c0 + tid]; }
+  // this thread always stages the same EPC channels: keep their BN scale/shift in registers (LDS is exactly 2 x 40 KiB,
+  // so two workgroups share a CU's 160 KiB)
+  float r_scale[EPC], r_shift[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    r_scale[e] = xform ? a.in_scale[c0 + chunk * EPC + e] : 1.f;
+    r_shift[e] = xform ? a.in_shift[c0 + chunk * EPC + e] : 0.f;
+  }
 
   const int step0 = blockIdx.z * steps_per_split;
   const int total_steps = (M + PS - 1) / PS;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int steps
         Elem<T>::unpack(v, f);
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-          float q = fmaf(f[e], s_scale[chunk * EPC + e], s_shift[chunk * EPC + e]);
+          float q = fmaf(f[e], r_scale[e], r_shift[e]);
           f[e] = a.in_relu ? fmaxf(q, 0.f) : q;
         }
         v = Elem<T>::pack(f);
@@ -108,7 +113,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int steps
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[t][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  if (xform) __syncthreads();
   load_regs(0);
   store_lds(0);
   __syncthreads();
@@ -116,43 +120,46 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a, int steps
     const bool more = s + 1 < nsteps;
     if (more) load_regs(s + 1);
     const char* b = smem + (s & 1) * BUF;
+    // wave w owns cin tile w and all four kout tiles: 4 A + TAPS B fragments feed 4*TAPS MFMAs per step
     if constexpr (BF) {
-      const bf16x8_t af = WgFrag<bf16_t>::load(b, 16 * wave, li, g);
+      bf16x8_t af[4];
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t)
+      for (int t4 = 0; t4 < 4; ++t4) af[t4] = WgFrag<bf16_t>::load(b, 16 * t4, li, g);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const bf16x8_t bfrag = WgFrag<bf16_t>::load(b + (1 + t) * TILE, 16 * c, li, g);
-          acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag, acc[t][c], 0, 0, 0);
-        }
+      for (int t = 0; t < TAPS; ++t) {
+        const bf16x8_t bfrag = WgFrag<bf16_t>::load(b + (1 + t) * TILE, 16 * wave, li, g);
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t4], bfrag, acc[t][t4], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int q = 0; q < PS / 4; ++q) {
         const int prow = 4 * q + g;
-        const float av = *reinterpret_cast<const float*>(b + prow * RB + (16 * wave + li) * 4);
+        float av[4];
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t)
+        for (int t4 = 0; t4 < 4; ++t4) av[t4] = *reinterpret_cast<const float*>(b + prow * RB + (16 * t4 + li) * 4);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float bv = *reinterpret_cast<const float*>(b + (1 + t) * TILE + prow * RB + (16 * c + li) * 4);
-            acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[t][c], 0, 0, 0);
-          }
+        for (int t = 0; t < TAPS; ++t) {
+          const float bv = *reinterpret_cast<const float*>(b + (1 + t) * TILE + prow * RB + (16 * wave + li) * 4);
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv, acc[t][t4], 0, 0, 0);
+        }
       }
     }
     if (more) store_lds((s + 1) & 1);
     __syncthreads();
   }
 
-  // D[row = kout 4g+j][col = cin li]  ->  dW[k][tap][c]
+  // acc[tap][t4]: D[row = kout 16*t4+4g+j][col = cin 16*wave+li]  ->  dW[k][tap][c]
   const int RS = a.R * a.S;
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int k = k0 + 16 * wave + 4 * g + j;
-        atomicAdd(a.dw + ((size_t)k * RS + t) * a.C + c0 + 16 * c + li, acc[t][c][j]);
+        const int k = k0 + 16 * t4 + 4 * g + j;
+        atomicAdd(a.dw + ((size_t)k * RS + t) * a.C + c0 + 16 * wave + li, acc[t][t4][j]);
       }
 }
 
@@ -168,7 +175,7 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
   if (splits < 1) splits = 1;
   const int sps = cdiv(total_steps, splits);
   splits = cdiv(total_steps, sps);
-  const size_t lds = 2 * (1 + TAPS) * 4096 + 2 * 64 * sizeof(float);
+  const size_t lds = 2 * (1 + TAPS) * 4096;
   auto kern = wgrad_kernel<T, TAPS>;
   static bool attr_done = false;
   if (!attr_done) {

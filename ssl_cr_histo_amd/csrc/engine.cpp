@@ -290,6 +290,7 @@ int pack_conv_layer(sslcr_net* n, ConvL& L, const BnL& bn, int mode, hipStream_t
   if (mode & 1) {
     a.w_fwd = L.w_fwd;
     a.w_dgrad = stem ? nullptr : L.w_dg;
+    a.dgrad_flip = (L.k == 3 && L.stride == 1);     // stride-1 dgrad runs as a plain 3x3 conv of dY (halo kernel)
     TRY(stem ? launch_pack_stem(dt, a, st) : launch_pack_conv(dt, a, st));
   }
   if (mode & 2) {
@@ -683,7 +684,7 @@ int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pa
     TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
     {
       ConvArgs a = conv_args(B.c2, dRaw2, B.c2.w_dg, dAct1, N, oh, ow);      // dgrad 3x3/1: gather over dRaw2 [.,K] with [C][R][S][K]
-      a.C = B.c2.cout; a.K = B.c2.cin; a.transposed = 1; a.PH = oh; a.PW = ow; a.OH = oh; a.OW = ow;
+      a.C = B.c2.cout; a.K = B.c2.cin; a.transposed = 0; a.PH = oh; a.PW = ow; a.OH = oh; a.OW = ow;   // flipped pack
       TRY(prof_conv(c, dt,a, st));
     }
     TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, 1, dRaw1, nullptr, opix, (double)opix, st));
@@ -691,7 +692,7 @@ int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pa
     if (B.has_ds) TRYI(wgrad_call(n, B.ds, X, dRawD, nullptr, N, xh, xw, oh, ow, st));
     if (need_dx) {
       ConvArgs a = conv_args(B.c1, dRaw1, B.c1.w_dg, dXin, N, oh, ow);
-      a.C = B.c1.cout; a.K = B.c1.cin; a.transposed = 1; a.PH = xh; a.PW = xw; a.OH = xh; a.OW = xw;
+      a.C = B.c1.cout; a.K = B.c1.cin; a.transposed = (B.c1.stride == 1) ? 0 : 1; a.PH = xh; a.PW = xw; a.OH = xh; a.OW = xw;
       if (!B.has_ds) a.residual = G;
       TRY(prof_conv(c, dt,a, st));
       if (B.has_ds) {       // 1x1/2 projection: scatter-accumulate into the even positions of dXin

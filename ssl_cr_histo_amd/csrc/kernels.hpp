@@ -24,6 +24,14 @@ using PackArgs = sslcr_pack_desc;
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st);
 int conv_tile_bp(const ConvArgs& a);
 int conv_partials_rows(const ConvArgs& a);
+// conv_halo.hip
+int conv_halo_tw(int dtype, const ConvArgs& a);
+int conv_halo_tiles(const ConvArgs& a, int tw);
+hipError_t launch_conv_halo(int dtype, const ConvArgs& a, int tw, hipStream_t st);
+// conv_halo256.hip
+int conv_halo256_mode(int dtype, const ConvArgs& a);
+int conv_halo256_tiles(const ConvArgs& a, int mode);
+hipError_t launch_conv_halo256(int dtype, const ConvArgs& a, int mode, hipStream_t st);
 // conv_wgrad.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, hipStream_t st);

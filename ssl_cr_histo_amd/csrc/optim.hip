@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const PackArgs a) {
       if (a.gamma) f = a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
       Elem<T>::st(reinterpret_cast<T*>(a.w_fwd) + i, w * f);
     }
-    if (a.w_dgrad) Elem<T>::st(reinterpret_cast<T*>(a.w_dgrad) + ((size_t)c * RS + rs) * a.K + k, w);
+    if (a.w_dgrad) Elem<T>::st(reinterpret_cast<T*>(a.w_dgrad) + ((size_t)c * RS + (a.dgrad_flip ? RS - 1 - rs : rs)) * a.K + k, w);
   }
   if (a.gamma && a.bias_out) {
     for (int k = blockIdx.x * 256 + threadIdx.x; k < a.K; k += gridDim.x * 256) {

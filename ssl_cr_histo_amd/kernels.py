@@ -70,7 +70,7 @@ def conv2d_wgrad(x, dy, dw, R, S, stride, pad, *, in_scale=None, in_shift=None, 
     L.check(L.lib().sslcr_conv2d_wgrad(_dt(x), d, L.stream_ptr()))
 
 
-def pack_conv(w_kcrs, dtype, *, fwd=True, dgrad=False, bn=None, eps=1e-5):
+def pack_conv(w_kcrs, dtype, *, fwd=True, dgrad=False, bn=None, eps=1e-5, dgrad_flip=False):
     """PyTorch [K,C,R,S] fp32 -> (w_fwd [K,R,S,C], w_dgrad [C,R,S,K], bias[K]|None) in engine dtype.
     bn = (gamma, beta, running_mean, running_var) folds eval-mode BatchNorm into w_fwd/bias."""
     _chk(w_kcrs)
@@ -81,7 +81,7 @@ def pack_conv(w_kcrs, dtype, *, fwd=True, dgrad=False, bn=None, eps=1e-5):
     bias = torch.empty(K, dtype=torch.float32, device=dev) if bn is not None else None
     g, b, rm, rv = bn if bn is not None else (None, None, None, None)
     d = L.PackDesc(L.ptr(w_kcrs), L.ptr(wf), L.ptr(wd), L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), eps, L.ptr(bias),
-                   K, C, R, S)
+                   K, C, R, S, int(dgrad_flip))
     L.check(L.lib().sslcr_pack_conv(dtype, d, L.stream_ptr()))
     return wf, wd, bias
 
@@ -92,7 +92,7 @@ def pack_stem(w_kcrs, dtype, *, bn=None, eps=1e-5):
     wf = torch.empty((64, 7, 8, 4), dtype=tdtype(dtype), device=dev)
     bias = torch.empty(64, dtype=torch.float32, device=dev) if bn is not None else None
     g, b, rm, rv = bn if bn is not None else (None, None, None, None)
-    d = L.PackDesc(L.ptr(w_kcrs), L.ptr(wf), None, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), eps, L.ptr(bias), 64, 3, 7, 7)
+    d = L.PackDesc(L.ptr(w_kcrs), L.ptr(wf), None, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), eps, L.ptr(bias), 64, 3, 7, 7, 0)
     L.check(L.lib().sslcr_pack_stem(dtype, d, L.stream_ptr()))
     return wf, bias
 

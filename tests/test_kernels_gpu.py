@@ -69,6 +69,12 @@ CONV_CASES = [
     (40, 32, 32, 64, 64, 3, 1, 1),     # M = 40960 < 65536 -> 64-pixel tiles ; many tiles
     (72, 32, 32, 64, 128, 3, 1, 1),    # M = 73728 -> 128-pixel tiles, K=128 config
     (70, 32, 32, 64, 64, 3, 1, 1),     # 128x64 config
+    (2, 8, 8, 512, 512, 3, 1, 1),      # halo kernel, 8-wide rows (2 images per tile), 8 channel slabs, BKO 128
+    (4, 8, 8, 64, 64, 3, 1, 1),        # halo kernel, 8-wide, single slab
+    (2, 16, 32, 128, 128, 3, 1, 1),    # halo kernel, 16-wide, 2 slabs
+    (3, 24, 48, 64, 128, 3, 1, 1),     # halo kernel, several tiles per image
+    (4, 8, 8, 512, 512, 3, 1, 1),      # 256-pixel halo kernel, 4 images x 8x8, 8 slabs
+    (2, 32, 32, 128, 256, 3, 1, 1),    # 256-pixel halo kernel, 16x16 tiles, 2 slabs
 ]
 
 
@@ -89,9 +95,11 @@ def test_conv_fwd_raw_stats(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-def test_conv_fwd_fused_prologue_epilogue(dtype):
+@pytest.mark.parametrize("shape", [(2, 12, 12, 128, 128), (2, 16, 16, 128, 128), (2, 8, 8, 256, 64), (4, 8, 8, 256, 128),
+                                   (1, 24, 16, 64, 64)])   # generic / halo256-16 / halo128-8 / halo256-8 / halo128-16
+def test_conv_fwd_fused_prologue_epilogue(shape, dtype):
     K = _k()
-    N, H, W, C, Ko = 2, 12, 12, 128, 128
+    N, H, W, C, Ko = shape
     x = q(rnd(3, (N, H, W, C)), dtype)
     w = q(rnd(4, (Ko, 3, 3, C), 0.05), dtype)
     sc, sh = rnd(5, (C,)).abs() + 0.5, rnd(6, (C,))
@@ -127,6 +135,12 @@ def test_conv_dgrad(case, dtype):
         dx = K.conv2d(to_dev(dy, dtype), to_dev(wd, dtype), stride, pad, transposed=True, pixel_hw=(H, W),
                       residual=to_dev(res, dtype))
         close(dx, want + res, TOL[dtype], "dgrad")
+        if stride == 1:
+            # the engine's form: tap-flipped [C][R][S][K] pack => the dgrad is a plain 3x3 conv of dY (halo kernel when it tiles)
+            w_kcrs = w.permute(0, 3, 1, 2).contiguous()
+            _, wdf, _ = K.pack_conv(w_kcrs.to(DEV), dtype, fwd=False, dgrad=True, dgrad_flip=True)
+            dx2 = K.conv2d(to_dev(dy, dtype), wdf, 1, 1, residual=to_dev(res, dtype))
+            close(dx2, want + res, TOL[dtype], "dgrad via flipped pack")
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
