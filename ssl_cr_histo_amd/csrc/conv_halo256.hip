@@ -26,17 +26,21 @@ template <> struct MmaQ<float> {
   }
 };
 
-template <typename T, int TW, int BKO>
-__global__ __launch_bounds__(512, 2) void conv3x3_halo256_kernel(const ConvArgs a) {
+// WK = waves along kouts (2: 512 threads, each wave 64 px x BKO/2 kouts; 1: 256 threads, each wave 64 px x BKO kouts --
+// used for K = 64 so that a wave still owns a 64x64 register tile and LDS reads stay at 16 MAC per byte)
+// ONE = the layer has a single channel slab (C == 64 bf16): no halo prefetch registers are kept across the tap loop
+template <typename T, int TW, int BKO, int WK, bool ONE>
+__global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const ConvArgs a) {
+  constexpr int NT = 256 * WK;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int CE = 8 * EPC;
   constexpr int TH = TW;                      // 16x16 tile of one image, or 8x8 tiles of four images
   constexpr int NI = 256 / (TH * TW);
   constexpr int HH = TH + 2, HWD = TW + 2;
   constexpr int HP = NI * HH * HWD;           // 324 or 400 halo pixels
-  constexpr int NLD = (HP * 8 + 511) / 512;   // 16-byte halo staging loads per thread
-  constexpr int WLD = BKO * 8 / 512;          // 16-byte weight staging loads per thread per tap (1 or 2)
-  constexpr int TK = BKO / 32, TP = 4;
+  constexpr int NLD = (HP * 8 + NT - 1) / NT;   // 16-byte halo staging loads per thread
+  constexpr int WLD = BKO * 8 / NT;          // 16-byte weight staging loads per thread per tap (1 or 2)
+  constexpr int TK = BKO / (16 * WK), TP = 4;
   constexpr int HBUF = HP * 128, WBUF = BKO * 128;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_halo = smem;
@@ -56,13 +60,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo256_kernel(const ConvArgs 
   const int k0 = blockIdx.y * BKO;
   const bool xform = a.in_scale != nullptr;
   if (xform)
-    for (int c = tid; c < a.C; c += 512) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
+    for (int c = tid; c < a.C; c += NT) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
 
   const int chunk = tid & 7;
   int src_off[NLD], dst_off[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    const int hp = (tid >> 3) + 64 * i;
+    const int hp = (tid >> 3) + (NT / 8) * i;
     if (hp < HP) {
       const int ni = hp / (HH * HWD), rem = hp - ni * (HH * HWD);
       const int hr = rem / HWD, hc = rem - hr * HWD;
@@ -109,14 +113,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo256_kernel(const ConvArgs 
   auto load_w = [&](int slab, int tap) {
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
-      const int row = (tid >> 3) + 64 * i;
+      const int row = (tid >> 3) + (NT / 8) * i;
       wreg[i] = ld16(wg + (((size_t)(k0 + row) * 9 + tap) * a.C + slab * CE + chunk * EPC) * sizeof(T));
     }
   };
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
-      const int row = (tid >> 3) + 64 * i;
+      const int row = (tid >> 3) + (NT / 8) * i;
       if (row < BKO) st16(s_w + buf * WBUF + row * 128 + ((chunk ^ (row & 7)) << 4), wreg[i]);
     }
   };
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo256_kernel(const ConvArgs 
   }
   int arow[TK];
 #pragma unroll
-  for (int t = 0; t < TK; ++t) arow[t] = wk * (BKO / 2) + (li >> 2) * (4 * TK) + t * 4 + (li & 3);
+  for (int t = 0; t < TK; ++t) arow[t] = wk * (BKO / WK) + (li >> 2) * (4 * TK) + t * 4 + (li & 3);
 
   f32x4_t acc[TK][TP];
 #pragma unroll
@@ -143,14 +147,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo256_kernel(const ConvArgs 
 
   if (xform) __syncthreads();
   load_halo(0);
-  if (BKO * 8 >= 512 || tid < BKO * 8) load_w(0, 0);
+  load_w(0, 0);
   store_halo(0);
   store_w(0);
   __syncthreads();
 
   int wb = 0;
   for (int slab = 0; slab < nslabs; ++slab) {
-    const bool more = slab + 1 < nslabs;
+    const bool more = ONE ? false : (slab + 1 < nslabs);
     if (more) load_halo(slab + 1);            // in flight during the nine taps of this slab
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo256_kernel(const ConvArgs 
   }
 
   // ---------------- epilogue
-  const int kb = k0 + wk * (BKO / 2) + g * (4 * TK);
+  const int kb = k0 + wk * (BKO / WK) + g * (4 * TK);
   float bias[4 * TK];
 #pragma unroll
   for (int j = 0; j < 4 * TK; ++j) bias[j] = a.bias ? a.bias[kb + j] : 0.f;
@@ -257,11 +261,11 @@ int conv_halo256_tiles(const ConvArgs& a, int mode) {
   return mode == 16 ? a.N * (a.H / 16) * (a.W / 16) : a.N / 4;
 }
 
-template <typename T, int TW, int BKO>
+template <typename T, int TW, int BKO, int WK, bool ONE>
 static hipError_t launch_q(const ConvArgs& a, hipStream_t st) {
   constexpr int HP = (256 / (TW * TW)) * (TW + 2) * (TW + 2);
   const size_t lds = HP * 128 + 2 * BKO * 128 + 2 * a.C * sizeof(float);
-  auto kern = conv3x3_halo256_kernel<T, TW, BKO>;
+  auto kern = conv3x3_halo256_kernel<T, TW, BKO, WK, ONE>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -269,15 +273,20 @@ static hipError_t launch_q(const ConvArgs& a, hipStream_t st) {
     attr_done = true;
   }
   dim3 grid(conv_halo256_tiles(a, TW), a.K / BKO);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(256 * WK), lds, st, a);
   return hipGetLastError();
 }
 
 template <typename T>
 static hipError_t launch_qt(const ConvArgs& a, int mode, hipStream_t st) {
   const bool wide = a.K % 128 == 0;
-  if (mode == 16) return wide ? launch_q<T, 16, 128>(a, st) : launch_q<T, 16, 64>(a, st);
-  return wide ? launch_q<T, 8, 128>(a, st) : launch_q<T, 8, 64>(a, st);
+  const bool one = a.C == 8 * Elem<T>::EPC;
+  if (mode == 16) {
+    if (wide) return launch_q<T, 16, 128, 2, false>(a, st);
+    return one ? launch_q<T, 16, 64, 1, true>(a, st) : launch_q<T, 16, 64, 2, false>(a, st);
+  }
+  if (wide) return launch_q<T, 8, 128, 2, false>(a, st);
+  return one ? launch_q<T, 8, 64, 1, true>(a, st) : launch_q<T, 8, 64, 2, false>(a, st);
 }
 
 hipError_t launch_conv_halo256(int dtype, const ConvArgs& a, int mode, hipStream_t st) {

@@ -202,6 +202,8 @@ hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t*
 }
 
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st) {
+  const int tw = wgrad_halo_tw(a);
+  if (tw) return launch_wgrad_halo(dtype, a, tw, st);
   const bool three = a.R == 3;
   if (dtype == DT_BF16) return three ? launch_w<bf16_t, 9>(a, st) : launch_w<bf16_t, 1>(a, st);
   return three ? launch_w<float, 9>(a, st) : launch_w<float, 1>(a, st);

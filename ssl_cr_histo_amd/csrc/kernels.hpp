@@ -34,6 +34,8 @@ int conv_halo256_tiles(const ConvArgs& a, int mode);
 hipError_t launch_conv_halo256(int dtype, const ConvArgs& a, int mode, hipStream_t st);
 // conv_wgrad.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
+int wgrad_halo_tw(const WgradArgs& a);
+hipError_t launch_wgrad_halo(int dtype, const WgradArgs& a, int tw, hipStream_t st);
 hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, hipStream_t st);
 // stem.hip
 hipError_t launch_stem(int dtype, const StemArgs& a, hipStream_t st);

@@ -1,0 +1,231 @@
+// Weight gradient of the 3x3 / stride 1 / pad 1 convs, LDS-halo form.
+//
+//   dW[k][r][s][c] += sum_{pixels} dY[pix][k] * act(X)[pix + (r-1, s-1)][c]
+//
+// The gather form (conv_wgrad.hip) re-stages the shifted input once per tap: 40 KiB of global->LDS traffic per 32 pixels,
+// which is the LDS-write / L1 limit, not the matrix pipe.  Here a workgroup walks 128-pixel tiles (8x16, or two 8x8
+// images); per tile it stages the dY tile and ONE (8+2)x(TW+2) input halo (producer BatchNorm+ReLU applied on the way) and
+// all nine taps fetch their B fragments from the halo at shifted pixel addresses -- ds_read_b64_tr_b16 takes a per-lane
+// address, so the shift is free.  4.3x less staging traffic per MAC.  Same 64(kout) x 64(cin) x 9 register tile, wave w
+// owning cin tile w; fp32 hardware atomics into dW.
+#include "kernels.hpp"
+
+namespace sslcr {
+
+typedef short h16x4_t __attribute__((ext_vector_type(4)));
+typedef short h16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
+  h16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4_t*)(p0));
+  h16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) h16x4_t*)(p1));
+  h16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <typename T, int TW>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a, int tiles_per_split, int ntiles) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr bool BF = Elem<T>::DT == DT_BF16;
+  constexpr int RB = 64 * sizeof(T);            // LDS bytes per pixel row (64 channels)
+  constexpr int CPR = RB / 16;                  // 16-byte chunks per row (8 / 16)
+  constexpr int TH = 8;
+  constexpr int NI = 128 / (TH * TW);
+  constexpr int HH = TH + 2, HWD = TW + 2;
+  constexpr int HP = NI * HH * HWD;             // 180 / 200 halo pixels
+  constexpr int YL = 128 * CPR / 256;           // dY staging loads per thread (4 / 8)
+  constexpr int HL = (HP * CPR + 255) / 256;    // halo staging loads per thread
+  constexpr int YBUF = 128 * RB, HBUF = HP * RB;
+  constexpr int BUF = YBUF + HBUF;
+  constexpr int NBUF = BF ? 2 : 1;              // fp32 parity mode: single-buffered (LDS capacity)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int chunk = tid % CPR, prow = tid / CPR;          // staging role
+  const bool xform = a.in_scale != nullptr;
+  float r_scale[EPC], r_shift[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    r_scale[e] = xform ? a.in_scale[c0 + chunk * EPC + e] : 1.f;
+    r_shift[e] = xform ? a.in_shift[c0 + chunk * EPC + e] : 0.f;
+  }
+  const int tiles_w = a.W / TW, tiles_h = a.H / TH;
+  const int t_begin = blockIdx.z * tiles_per_split;
+  int t_end = t_begin + tiles_per_split;
+  if (t_end > ntiles) t_end = ntiles;
+  if (t_begin >= t_end) return;
+  const char* xg = reinterpret_cast<const char*>(a.x);
+  const char* dyg = reinterpret_cast<const char*>(a.dy);
+
+  u32x4_t yreg[YL], hreg[HL];
+  unsigned hin = 0;
+  auto load_regs = [&](int tile) {
+    int t = tile;
+    const int tw_i = t % tiles_w; t /= tiles_w;
+    const int th_i = t % tiles_h;
+    const int n0 = (t / tiles_h) * NI;
+    const int h0 = th_i * TH, w0 = tw_i * TW;
+#pragma unroll
+    for (int i = 0; i < YL; ++i) {
+      const int p = prow + (256 / CPR) * i;                 // pixel of the tile
+      const int ni = p / (TH * TW), rem = p - ni * (TH * TW);
+      const int ph = rem / TW, pw = rem - ph * TW;
+      const size_t pix = ((size_t)(n0 + ni) * a.H + h0 + ph) * a.W + w0 + pw;
+      yreg[i] = ld16(dyg + (pix * a.K + k0 + chunk * EPC) * sizeof(T));
+    }
+    hin = 0;
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+      const int hp = prow + (256 / CPR) * i;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (hp < HP) {
+        const int ni = hp / (HH * HWD), rem = hp - ni * (HH * HWD);
+        const int hr = rem / HWD, hc = rem - hr * HWD;
+        const int h = h0 - 1 + hr, w = w0 - 1 + hc;
+        if (h >= 0 && w >= 0 && h < a.H && w < a.W) {
+          v = ld16(xg + ((((size_t)(n0 + ni) * a.H + h) * a.W + w) * a.C + c0 + chunk * EPC) * sizeof(T));
+          hin |= 1u << i;
+        }
+      }
+      hreg[i] = v;
+    }
+  };
+  auto store_lds = [&](int buf) {
+    char* yb = smem + buf * BUF;
+    char* hb = yb + YBUF;
+#pragma unroll
+    for (int i = 0; i < YL; ++i) st16(yb + (prow + (256 / CPR) * i) * RB + chunk * 16, yreg[i]);
+#pragma unroll
+    for (int i = 0; i < HL; ++i) {
+      const int hp = prow + (256 / CPR) * i;
+      if (hp >= HP) continue;
+      u32x4_t v = hreg[i];
+      if (xform && ((hin >> i) & 1u)) {
+        float f[EPC];
+        Elem<T>::unpack(v, f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float q = fmaf(f[e], r_scale[e], r_shift[e]);
+          f[e] = a.in_relu ? fmaxf(q, 0.f) : q;
+        }
+        v = Elem<T>::pack(f);
+      }
+      st16(hb + hp * RB + chunk * 16, v);
+    }
+  };
+
+  f32x4_t acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // halo pixel index of tile pixel p, tap (0,0)
+  auto hpix = [&](int p) {
+    if (TW == 16) return (p >> 4) * HWD + (p & 15);
+    return (p >> 6) * (HH * HWD) + ((p >> 3) & 7) * HWD + (p & 7);
+  };
+
+  load_regs(t_begin);
+  store_lds(0);
+  __syncthreads();
+  int buf = 0;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const bool more = tile + 1 < t_end;
+    if (more) load_regs(tile + 1);
+    const char* yb = smem + buf * BUF;
+    const char* hb = yb + YBUF;
+    if constexpr (BF) {
+#pragma unroll 1
+      for (int q = 0; q < 4; ++q) {              // 32-pixel MFMA depth steps of the 128-pixel tile (not unrolled: registers)
+        const int p0 = q * 32 + 8 * g + (li >> 2);          // this lane's source pixels for the transpose reads
+        bf16x8_t af[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const char* pa = yb + p0 * RB + (16 * t4 + (li & 3) * 4) * 2;
+          af[t4] = tr_pair(pa, pa + 4 * RB);
+        }
+        const int h0p = hpix(p0), h1p = hpix(p0 + 4);
+        const int coff = (16 * wave + (li & 3) * 4) * 2;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int toff = (t / 3) * HWD + (t % 3);
+          const bf16x8_t bfrag = tr_pair(hb + (h0p + toff) * RB + coff, hb + (h1p + toff) * RB + coff);
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t4], bfrag, acc[t][t4], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (int q = 0; q < 32; ++q) {             // 4-pixel fp32 MFMA depth steps
+        const int p = 4 * q + g;
+        float av[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) av[t4] = *reinterpret_cast<const float*>(yb + p * RB + (16 * t4 + li) * 4);
+        const int hp0 = hpix(p);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int toff = (t / 3) * HWD + (t % 3);
+          const float bv = *reinterpret_cast<const float*>(hb + (hp0 + toff) * RB + (16 * wave + li) * 4);
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv, acc[t][t4], 0, 0, 0);
+        }
+      }
+    }
+    if (NBUF == 1) __syncthreads();             // single buffer: everyone is done reading before it is overwritten
+    if (more) store_lds(NBUF == 2 ? buf ^ 1 : 0);
+    __syncthreads();
+    if (NBUF == 2) buf ^= 1;
+  }
+
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 16 * t4 + 4 * g + j;
+        atomicAdd(a.dw + ((size_t)k * 9 + t) * a.C + c0 + 16 * wave + li, acc[t][t4][j]);
+      }
+}
+
+int wgrad_halo_tw(const WgradArgs& a) {
+  if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.OH != a.H || a.OW != a.W) return 0;
+  if (a.C % 64 != 0 || a.K % 64 != 0 || a.H % 8 != 0) return 0;
+  if (a.W % 16 == 0) return 16;
+  if (a.W % 8 == 0 && a.N % 2 == 0) return 8;
+  return 0;
+}
+
+template <typename T, int TW>
+static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
+  constexpr bool BF = Elem<T>::DT == DT_BF16;
+  constexpr int NI = 128 / (8 * TW);
+  constexpr int HP = NI * 10 * (TW + 2);
+  const int ntiles = (a.N / NI) * (a.H / 8) * (a.W / TW);
+  const int kc = (a.K / 64) * (a.C / 64);
+  int splits = cdiv(1024, kc);
+  const int max_splits = cdiv(ntiles, 2);                 // at least 2 tiles (256 pixels) per workgroup
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int tps = cdiv(ntiles, splits);
+  splits = cdiv(ntiles, tps);
+  const size_t lds = (size_t)(BF ? 2 : 1) * (128 + HP) * 64 * sizeof(T);
+  auto kern = wgrad3x3_halo_kernel<T, TW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.K / 64, a.C / 64, splits), dim3(256), lds, st, a, tps, ntiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_wgrad_halo(int dtype, const WgradArgs& a, int tw, hipStream_t st) {
+  if (dtype == DT_BF16) return tw == 16 ? launch_wh<bf16_t, 16>(a, st) : launch_wh<bf16_t, 8>(a, st);
+  return tw == 16 ? launch_wh<float, 16>(a, st) : launch_wh<float, 8>(a, st);
+}
+
+}  // namespace sslcr

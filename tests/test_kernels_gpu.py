@@ -145,7 +145,8 @@ def test_conv_dgrad(case, dtype):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 9, 11, 64, 128, 3, 2, 1), (2, 8, 8, 128, 256, 1, 2, 0),
-                                  (5, 12, 12, 128, 64, 3, 1, 1)])
+                                  (5, 12, 12, 128, 64, 3, 1, 1), (4, 8, 8, 128, 128, 3, 1, 1), (3, 24, 32, 64, 128, 3, 1, 1),
+                                  (6, 8, 8, 512, 64, 3, 1, 1)])    # last three: halo wgrad, 8-wide / 16-wide tiles
 def test_conv_wgrad(case, dtype):
     K = _k()
     N, H, W, C, Ko, Rr, stride, pad = case
