@@ -42,6 +42,9 @@ typedef struct sslcr_conv_desc {
   int OH, OW, osh;        /* physical output dims; pixel (ph,pw) is stored at (ph*osh, pw*osh) */
   int transposed;         /* 0: src = p*stride-pad+r ; 1 (dgrad): src = (p+pad-r)/stride when divisible */
   int in_relu, relu, accumulate;
+  int pix_mul, pix_off_h, pix_off_w;   /* sub-lattice of the pixel space: pixel (i,j) of the PH x PW grid is (i*mul+off_h, j*mul+off_w);
+                                          mul = 0 means 1.  With tap_mask this runs ONE parity class of a strided dgrad */
+  unsigned tap_mask;                   /* bit (r*S+s) set = visit that tap; 0 = all taps */
 } sslcr_conv_desc;
 int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream);
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d);

@@ -80,6 +80,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ u32x4_t ld16(const void* p) { return *reinterpret_cast<const u32x4_t*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4_t& v) { *reinterpret_cast<u32x4_t*>(p) = v; }
 
+// Weight tiles sit in LDS in MFMA-fragment order: kout row r = q*(4TK) + t*4 + j of a 16*TK-row block (q = fragment lane>>2,
+// t = MFMA tile, j = lane&3 -- the permutation that gives a lane 4*TK consecutive output channels) is stored at row
+// t*16 + q*4 + j, so the 16 lanes of a fragment read 16 CONSECUTIVE LDS rows and the (row&7) XOR swizzle is conflict-free
+// (kept in kout order the 16 rows alias 4-fold on the swizzle key).
+template <int TK>
+__device__ __forceinline__ int wperm(int r) {
+  constexpr int B = 16 * TK;
+  const int blk = r / B, x = r - blk * B;
+  const int q = x / (4 * TK), y = x - q * (4 * TK);
+  return blk * B + (y >> 2) * 16 + q * 4 + (y & 3);
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace sslcr

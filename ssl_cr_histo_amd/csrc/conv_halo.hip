@@ -85,6 +85,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
   };
   auto store_halo = [&](int slab, int buf) {
     char* hb = smem + buf * HBUF;
+    // this thread's EPC channels of the slab: read scale/shift ONCE (the compiler cannot hoist LDS reads over the LDS stores)
+    float sc[EPC], sh[EPC];
+    if (xform) {
+      const int cb = slab * CE + chunk * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { sc[e] = s_scale[cb + e]; sh[e] = s_shift[cb + e]; }
+    }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       if (src_off[i] == -2) continue;
@@ -92,10 +99,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
       if (xform && src_off[i] >= 0) {
         float f[EPC];
         Elem<T>::unpack(v, f);
-        const int cb = slab * CE + chunk * EPC;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-          float t = fmaf(f[e], s_scale[cb + e], s_shift[cb + e]);
+          float t = fmaf(f[e], sc[e], sh[e]);
           f[e] = a.in_relu ? fmaxf(t, 0.f) : t;
         }
         v = Elem<T>::pack(f);
@@ -238,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
 
 // usable when: plain 3x3/1 pad 1, same-size output, no scatter/accumulate, spatial dims tile exactly
 int conv_halo_tw(int dtype, const ConvArgs& a) {
+  if (a.pix_mul > 1 || a.tap_mask) return 0;
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.transposed || a.accumulate || a.osh != 1) return 0;
   if (a.PH != a.H || a.PW != a.W || a.OH != a.H || a.OW != a.W) return 0;
   const int ce = dtype == DT_BF16 ? 64 : 32;

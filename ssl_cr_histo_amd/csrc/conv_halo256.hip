@@ -91,6 +91,13 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
     }
   };
   auto store_halo = [&](int slab) {
+    // this thread's EPC channels of the slab: read scale/shift ONCE (the compiler cannot hoist LDS reads over the LDS stores)
+    float sc[EPC], sh[EPC];
+    if (xform) {
+      const int cb = slab * CE + chunk * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { sc[e] = s_scale[cb + e]; sh[e] = s_shift[cb + e]; }
+    }
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       if (src_off[i] == -2) continue;
@@ -98,10 +105,9 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
       if (xform && src_off[i] >= 0) {
         float f[EPC];
         Elem<T>::unpack(v, f);
-        const int cb = slab * CE + chunk * EPC;
 #pragma unroll
         for (int e = 0; e < EPC; ++e) {
-          float t = fmaf(f[e], s_scale[cb + e], s_shift[cb + e]);
+          float t = fmaf(f[e], sc[e], sh[e]);
           f[e] = a.in_relu ? fmaxf(t, 0.f) : t;
         }
         v = Elem<T>::pack(f);
@@ -120,8 +126,8 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < WLD; ++i) {
-      const int row = (tid >> 3) + (NT / 8) * i;
-      if (row < BKO) st16(s_w + buf * WBUF + row * 128 + ((chunk ^ (row & 7)) << 4), wreg[i]);
+      const int row = wperm<TK>((tid >> 3) + (NT / 8) * i);
+      st16(s_w + buf * WBUF + row * 128 + ((chunk ^ (row & 7)) << 4), wreg[i]);
     }
   };
 
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
   }
   int arow[TK];
 #pragma unroll
-  for (int t = 0; t < TK; ++t) arow[t] = wk * (BKO / WK) + (li >> 2) * (4 * TK) + t * 4 + (li & 3);
+  for (int t = 0; t < TK; ++t) arow[t] = wk * (BKO / WK) + t * 16 + li;      // fragment order (see wperm)
 
   f32x4_t acc[TK][TP];
 #pragma unroll
@@ -248,6 +254,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
 
 // 0: not applicable; 16: 16x16 tiles; 8: four images x 8x8
 int conv_halo256_mode(int dtype, const ConvArgs& a) {
+  if (a.pix_mul > 1 || a.tap_mask) return 0;
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.transposed || a.accumulate || a.osh != 1) return 0;
   if (a.PH != a.H || a.PW != a.W || a.OH != a.H || a.OW != a.W) return 0;
   const int ce = dtype == DT_BF16 ? 64 : 32;

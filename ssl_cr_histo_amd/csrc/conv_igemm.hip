@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int M = a.N * PHW;
   const int chunk = tid & 7, lrow = tid >> 3;
   const bool xform = a.in_scale != nullptr;
+  const int pmul = a.pix_mul ? a.pix_mul : 1;
 
   if (xform) {
     for (int c = tid; c < a.C; c += 256) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     if (m < M) {
       int n = m / PHW, rem = m - n * PHW;
       int ph = rem / a.PW, pw = rem - ph * a.PW;
+      ph = ph * pmul + a.pix_off_h; pw = pw * pmul + a.pix_off_w;
       pbase[i] = n * a.H * a.W;
       hb[i] = a.transposed ? ph + a.pad : ph * a.stride - a.pad;
       wb[i] = a.transposed ? pw + a.pad : pw * a.stride - a.pad;
@@ -75,15 +77,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const char* wg = reinterpret_cast<const char*>(a.w);
   const int RS = a.R * a.S;
   const int cslabs = a.C / CE;
-  const int nsteps = RS * cslabs;
+  const unsigned tmask = a.tap_mask ? a.tap_mask : ((1u << RS) - 1u);
+  const int nsteps = __builtin_popcount(tmask) * cslabs;
+  int it_tap = __builtin_ctz(tmask), it_slab = 0;      // load_regs() is called for steps 0,1,2,... in order
 
   u32x4_t preg[PR], wreg[WR];
   unsigned inb_mask = 0;
   int cur_c0 = 0;
 
-  auto load_regs = [&](int step) {
-    int tap = step / cslabs;
-    int c0 = (step - tap * cslabs) * CE;
+  auto load_regs = [&](int) {
+    const int tap = it_tap;
+    const int c0 = it_slab * CE;
+    if (++it_slab == cslabs) {
+      it_slab = 0;
+      do { ++it_tap; } while (it_tap < RS && !((tmask >> it_tap) & 1u));
+    }
     int r = tap / a.S, s = tap - r * a.S;
     cur_c0 = c0;
     inb_mask = 0;
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < WR; ++i) {
-      int row = lrow + 32 * i;
+      int row = wperm<TK>(lrow + 32 * i);
       st16(wbuf + row * 128 + ((chunk ^ (row & 7)) << 4), wreg[i]);
     }
   };
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       u32x4_t af[TK], bfr[TP];
 #pragma unroll
       for (int t = 0; t < TK; ++t) {
-        int row = wk * (BKO / 2) + (li >> 2) * (4 * TK) + t * 4 + (li & 3);
+        int row = wk * (BKO / 2) + t * 16 + li;            // fragment order (see wperm)
         af[t] = ld16(wbuf + row * 128 + ((ci ^ (row & 7)) << 4));
       }
 #pragma unroll
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     if (m >= M) continue;
     int n = m / PHW, rem = m - n * PHW;
     int ph = rem / a.PW, pw = rem - ph * a.PW;
+    ph = ph * pmul + a.pix_off_h; pw = pw * pmul + a.pix_off_w;
     size_t opix = ((size_t)n * a.OH + (size_t)ph * a.osh) * a.OW + (size_t)pw * a.osh;
     size_t off = (opix * a.K + kb) * sizeof(T);
     float v[4 * TK];

@@ -32,7 +32,8 @@ def _chk(*ts):
 
 
 def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bias=None, residual=None, relu=False,
-           want_stats=False, out=None, transposed=False, out_hw=None, osh=1, accumulate=False, pixel_hw=None):
+           want_stats=False, out=None, transposed=False, out_hw=None, osh=1, accumulate=False, pixel_hw=None,
+           pix_mul=0, pix_off=(0, 0), tap_mask=0):
     """x NHWC [N,H,W,C], w KRSC [K,R,S,C] -> y NHWC (+ partial stats [rows,2,K] fp32).
 
     transposed=True is the dgrad gather: pixel space = the conv's input (pixel_hw), x = dY, w = [C][R][S][K]."""
@@ -49,7 +50,7 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
     y = out if out is not None else torch.empty((N, OH, OW, K), dtype=x.dtype, device=x.device)
     d = L.ConvDesc(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(in_scale), L.ptr(in_shift), L.ptr(bias), L.ptr(residual), None,
                    N, H, W, C, K, R, S, stride, pad, PH, PW, OH, OW, osh, int(transposed), int(in_relu), int(relu),
-                   int(accumulate))
+                   int(accumulate), int(pix_mul), int(pix_off[0]), int(pix_off[1]), int(tap_mask))
     stats = None
     if want_stats:
         rows = L.lib().sslcr_conv2d_partial_rows(d)

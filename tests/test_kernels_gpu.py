@@ -135,6 +135,20 @@ def test_conv_dgrad(case, dtype):
         dx = K.conv2d(to_dev(dy, dtype), to_dev(wd, dtype), stride, pad, transposed=True, pixel_hw=(H, W),
                       residual=to_dev(res, dtype))
         close(dx, want + res, TOL[dtype], "dgrad")
+        if stride == 2:
+            # the engine's form: one launch per input-pixel parity class, visiting only that class's taps
+            dx3 = torch.zeros((N, H, W, C), dtype=K.tdtype(dtype), device=DEV)
+            for par in range(4):
+                ph_, pw_ = par >> 1, par & 1
+                m = 0
+                for r in range(3):
+                    for s2 in range(3):
+                        if (ph_ + 1 - r) % 2 == 0 and (pw_ + 1 - s2) % 2 == 0:
+                            m |= 1 << (r * 3 + s2)
+                K.conv2d(to_dev(dy, dtype), to_dev(wd, dtype), stride, pad, transposed=True, out=dx3, out_hw=(H, W),
+                         pixel_hw=((H - ph_ + 1) // 2, (W - pw_ + 1) // 2), residual=to_dev(res, dtype), pix_mul=2,
+                         pix_off=(ph_, pw_), tap_mask=m)
+            close(dx3, want + res, TOL[dtype], "dgrad by parity classes")
         if stride == 1:
             # the engine's form: tap-flipped [C][R][S][K] pack => the dgrad is a plain 3x3 conv of dY (halo kernel when it tiles)
             w_kcrs = w.permute(0, 3, 1, 2).contiguous()
