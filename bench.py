@@ -214,23 +214,27 @@ def main():
         for _ in range(max(2, min(5, args.steps))):
             step()
         torch.cuda.synchronize()
-        pr = [eng.profile_read(0), eng.profile_read(1)]
+        rows = eng.profile_table()          # per kernel template instance, sorted by total time
         eng.profile(False)
-        names = ["conv_igemm_kernel (forward + dgrad)", "wgrad_kernel"]
-        dom = 0 if pr[0]["ms"] >= pr[1]["ms"] else 1
         peak = 2500.0 if args.dtype == "bf16" else 157.3
-        if pr[dom]["launches"]:
-            ach = pr[dom]["flops"] / (pr[dom]["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": names[dom], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+        nprof = max(2, min(5, args.steps))
+        if rows:
+            d = rows[0]                       # the dominant kernel of the step
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": d["name"], "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(ach / peak, 4), "traffic": None,
-                               "launches": pr[dom]["launches"], "avg_launch_us": round(pr[dom]["ms"] * 1e3 / pr[dom]["launches"], 2),
-                               "algorithmic_gflop_per_launch": round(pr[dom]["flops"] / pr[dom]["launches"] / 1e9, 3),
-                               "algorithmic_gb_s": round(pr[dom]["bytes"] / (pr[dom]["ms"] * 1e-3) / 1e9, 1)}
-            oth = 1 - dom
-            if pr[oth]["launches"]:
-                out["roofline_other"] = {"kernel": names[oth], "achieved": round(pr[oth]["flops"] / (pr[oth]["ms"] * 1e-3) / 1e12, 2),
-                                         "unit": "TFLOP/s", "launches": pr[oth]["launches"], "ms": round(pr[oth]["ms"], 3)}
-            out["conv_time_share"] = round((pr[0]["ms"] + pr[1]["ms"]) / (ms_per_step * max(2, min(5, args.steps))), 3)
+                               "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                               "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+                               "algorithmic_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 2),
+                               "time_share_of_step": round(d["ms"] / (ms_per_step * nprof), 3)}
+            out["conv_kernels"] = [{"kernel": r["name"], "launches_per_step": r["launches"] // nprof,
+                                    "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                                    "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
+                                    "ms_per_step": round(r["ms"] / nprof, 3)} for r in rows]
+            tot_ms = sum(r["ms"] for r in rows)
+            tot_fl = sum(r["flops"] for r in rows)
+            out["conv_all"] = {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), "frac_of_peak": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
+                               "time_share_of_step": round(tot_ms / (ms_per_step * nprof), 3)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "ssl_cr":
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:

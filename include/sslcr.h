@@ -182,18 +182,20 @@ typedef struct sslcr_net sslcr_net;
 
 int sslcr_create(sslcr_ctx** out, int device, int dtype);
 int sslcr_destroy(sslcr_ctx* ctx);
-/* one process per GPU: rank 0 makes the 128-byte id, the host broadcasts it (torch.distributed), every rank inits.
+/* one process per GPU: rank 0 makes the 256-byte id pair, the host broadcasts it (torch.distributed), every rank inits.
  * With a communicator: gradients are all-reduced (bucketed, overlapped with backward) and train-mode BatchNorm uses
  * GLOBAL batch statistics (all-reduce of per-channel sums), which is what makes N ranks equal the single-device
  * reference (the reference's nn.DataParallel BN is per-replica, eval_BreastPathQ_SSL_CR.py:474-477). */
-int sslcr_comm_unique_id(void* id128);
-int sslcr_comm_init(sslcr_ctx* ctx, const void* id128, int rank, int world);
+int sslcr_comm_unique_id(void* id256);       /* two 128-byte RCCL ids: [0] BatchNorm sums (compute stream), [1] gradient buckets (side stream) */
+int sslcr_comm_init(sslcr_ctx* ctx, const void* id256, int rank, int world);
 
 /* measurement: bracket every conv launch of this ctx with HIP events on its own stream (bench.py roofline leg).
  * which = 0: conv_igemm (forward + dgrad), 1: wgrad.  out4 = {launches, total ms, algorithmic FLOPs, algorithmic bytes}.
  * sslcr_profile(ctx, 1) also clears the previous records. */
 int sslcr_profile(sslcr_ctx* ctx, int enable);
 int sslcr_profile_read(sslcr_ctx* ctx, int which, double* out4);
+/* per kernel template instance: lines "name|launches|total_ms|algorithmic_flops|algorithmic_bytes" (names as rocprofv3 prints them) */
+int sslcr_profile_dump(sslcr_ctx* ctx, char* buf, size_t n);
 
 typedef struct sslcr_net_desc {
   float* const* params;                    /* [nparams] device pointers, named_parameters() order of models/net.py:

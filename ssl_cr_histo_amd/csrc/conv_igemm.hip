@@ -297,6 +297,32 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t st) {
   return launch_cfg<T, 64, 64>(a, st);
 }
 
+// the template instance launch_conv() will pick, spelled like rocprofv3 prints it (minus the argument list)
+const char* conv_kernel_name(int dtype, const ConvArgs& a) {
+  const bool bf = dtype == DT_BF16;
+  const bool wide = a.K % 128 == 0;
+  const int q = conv_halo256_mode(dtype, a);
+  if (q && conv_halo256_mode(DT_BF16, a) == q) {
+    const bool one = a.C == (bf ? 64 : 32);
+    if (q == 16) {
+      if (wide) return bf ? "sslcr::conv3x3_halo256_kernel<unsigned short, 16, 128, 2, false>" : "sslcr::conv3x3_halo256_kernel<float, 16, 128, 2, false>";
+      if (one) return bf ? "sslcr::conv3x3_halo256_kernel<unsigned short, 16, 64, 1, true>" : "sslcr::conv3x3_halo256_kernel<float, 16, 64, 1, true>";
+      return bf ? "sslcr::conv3x3_halo256_kernel<unsigned short, 16, 64, 2, false>" : "sslcr::conv3x3_halo256_kernel<float, 16, 64, 2, false>";
+    }
+    if (wide) return bf ? "sslcr::conv3x3_halo256_kernel<unsigned short, 8, 128, 2, false>" : "sslcr::conv3x3_halo256_kernel<float, 8, 128, 2, false>";
+    if (one) return bf ? "sslcr::conv3x3_halo256_kernel<unsigned short, 8, 64, 1, true>" : "sslcr::conv3x3_halo256_kernel<float, 8, 64, 1, true>";
+    return bf ? "sslcr::conv3x3_halo256_kernel<unsigned short, 8, 64, 2, false>" : "sslcr::conv3x3_halo256_kernel<float, 8, 64, 2, false>";
+  }
+  const int tw = q ? 0 : conv_halo_tw(dtype, a);
+  if (tw && conv_halo_tw(DT_BF16, a) == tw) return bf ? "sslcr::conv3x3_halo_kernel<unsigned short, ...>" : "sslcr::conv3x3_halo_kernel<float, ...>";
+  const int bp = conv_tile_bp(a);
+  if (bp == 128) {
+    if (wide) return bf ? "sslcr::conv_igemm_kernel<unsigned short, 128, 128>" : "sslcr::conv_igemm_kernel<float, 128, 128>";
+    return bf ? "sslcr::conv_igemm_kernel<unsigned short, 128, 64>" : "sslcr::conv_igemm_kernel<float, 128, 64>";
+  }
+  return bf ? "sslcr::conv_igemm_kernel<unsigned short, 64, 64>" : "sslcr::conv_igemm_kernel<float, 64, 64>";
+}
+
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
   const int q = conv_halo256_mode(dtype, a);
   if (q && conv_halo256_mode(DT_BF16, a) == q) return launch_conv_halo256(dtype, a, q, st);

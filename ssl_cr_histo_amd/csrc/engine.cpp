@@ -2,6 +2,7 @@
 // backward, gradient all-reduce (RCCL, bucketed + overlapped), synced BatchNorm, fused optimizer.  One C call per
 // step; every kernel goes to the caller's stream.  See include/sslcr.h for the reference code each entry replaces.
 #include <rccl/rccl.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <vector>
@@ -97,6 +98,7 @@ struct PassState {
 struct ProfRec {
   hipEvent_t e0, e1;
   double flops, bytes;
+  const char* name;       // the kernel template instance that was launched
 };
 struct Profiler {               // optional HIP-event bracketing of the conv launches (bench.py roofline leg)
   bool on = false;
@@ -113,7 +115,9 @@ struct Profiler {               // optional HIP-event bracketing of the conv lau
 struct sslcr_ctx {
   Profiler prof;
   int device = 0, dtype = 0;
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr;      // BatchNorm-sum all-reduces, only ever used on the caller's (compute) stream
+  ncclComm_t comm_g = nullptr;    // gradient buckets, only ever used on comm_stream (one communicator per stream, like
+                                  // separate process groups: no cross-stream serialisation inside RCCL)
   int rank = 0, world = 1;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready[8], ev_done = nullptr;
@@ -167,6 +171,7 @@ hipError_t prof_conv(sslcr_ctx* c, int dt, const ConvArgs& a, hipStream_t st) {
   const double src = (double)a.N * a.H * a.W;
   r.flops = a.transposed ? 2.0 * src * a.C * a.K * rs : 2.0 * M * a.K * a.C * rs;
   r.bytes = (src * a.C + (double)a.K * rs * a.C + M * a.K * (a.residual ? 2.0 : 1.0) * (a.accumulate ? 2.0 : 1.0)) * es;
+  r.name = conv_kernel_name(dt, a);
   (void)hipEventRecord(r.e0, st);
   hipError_t e = launch_conv(dt, a, st);
   (void)hipEventRecord(r.e1, st);
@@ -181,6 +186,7 @@ hipError_t prof_wgrad(sslcr_ctx* c, int dt, const WgradArgs& a, hipStream_t st) 
   const double M = (double)a.N * a.OH * a.OW;
   r.flops = 2.0 * M * a.K * a.C * a.R * a.S;
   r.bytes = ((double)a.N * a.H * a.W * a.C + M * a.K) * es + (double)a.K * a.R * a.S * a.C * 4.0;
+  r.name = wgrad_kernel_name(dt, a);
   (void)hipEventRecord(r.e0, st);
   hipError_t e = launch_wgrad(dt, a, st);
   (void)hipEventRecord(r.e1, st);
@@ -636,7 +642,7 @@ int launch_bucket_allreduce(sslcr_net* n, int bucket, size_t lo, size_t hi, hipS
   TRY(hipEventRecord(c->ev_ready[bucket], st));
   TRY(hipStreamWaitEvent(c->comm_stream, c->ev_ready[bucket], 0));
   float* g = (float*)n->grads.p + lo;
-  TRYN(ncclAllReduce(g, g, hi - lo, ncclFloat, ncclSum, c->comm, c->comm_stream));
+  TRYN(ncclAllReduce(g, g, hi - lo, ncclFloat, ncclSum, c->comm_g, c->comm_stream));
   return 0;
 }
 
@@ -820,6 +826,7 @@ int sslcr_destroy(sslcr_ctx* c) {
   (void)hipDeviceSynchronize();
   if (c->comm) {
     ncclCommDestroy(c->comm);
+    if (c->comm_g) ncclCommDestroy(c->comm_g);
     (void)hipStreamDestroy(c->comm_stream);
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev_ready[i]);
     (void)hipEventDestroy(c->ev_done);
@@ -841,6 +848,31 @@ int sslcr_profile(sslcr_ctx* c, int enable) {
   return 0;
 }
 
+int sslcr_profile_dump(sslcr_ctx* c, char* buf, size_t n) {
+  if (!c || !buf || n < 64) return fail("sslcr_profile_dump: invalid argument");
+  TRY(hipDeviceSynchronize());
+  struct Row { const char* name; double launches, ms, flops, bytes; };
+  std::vector<Row> rows;
+  for (int w = 0; w < 2; ++w)
+    for (auto& r : c->prof.rec[w]) {
+      float t = 0.f;
+      TRY(hipEventElapsedTime(&t, r.e0, r.e1));
+      Row* hit = nullptr;
+      for (auto& q : rows)
+        if (strcmp(q.name, r.name) == 0) { hit = &q; break; }
+      if (!hit) { rows.push_back(Row{r.name, 0, 0, 0, 0}); hit = &rows.back(); }
+      hit->launches += 1; hit->ms += t; hit->flops += r.flops; hit->bytes += r.bytes;
+    }
+  size_t off = 0;
+  for (auto& q : rows) {
+    int k = snprintf(buf + off, n - off, "%s|%.0f|%.6f|%.6e|%.6e\n", q.name, q.launches, q.ms, q.flops, q.bytes);
+    if (k < 0 || (size_t)k >= n - off) return fail("sslcr_profile_dump: buffer too small");
+    off += k;
+  }
+  buf[off] = 0;
+  return 0;
+}
+
 int sslcr_profile_read(sslcr_ctx* c, int which, double* out4) {
   if (!c || !out4 || which < 0 || which > 1) return fail("sslcr_profile_read: invalid argument");
   TRY(hipDeviceSynchronize());
@@ -854,20 +886,23 @@ int sslcr_profile_read(sslcr_ctx* c, int which, double* out4) {
   return 0;
 }
 
-int sslcr_comm_unique_id(void* id128) {
-  if (!id128) return fail("sslcr_comm_unique_id: null");
+int sslcr_comm_unique_id(void* id256) {
+  if (!id256) return fail("sslcr_comm_unique_id: null");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
-  TRYN(ncclGetUniqueId((ncclUniqueId*)id128));
+  TRYN(ncclGetUniqueId((ncclUniqueId*)id256));
+  TRYN(ncclGetUniqueId((ncclUniqueId*)((char*)id256 + 128)));
   return 0;
 }
 
-int sslcr_comm_init(sslcr_ctx* c, const void* id128, int rank, int world) {
-  if (!c || !id128 || world < 1 || rank < 0 || rank >= world) return fail("sslcr_comm_init: invalid argument");
+int sslcr_comm_init(sslcr_ctx* c, const void* id256, int rank, int world) {
+  if (!c || !id256 || world < 1 || rank < 0 || rank >= world) return fail("sslcr_comm_init: invalid argument");
   if (world == 1) { c->rank = 0; c->world = 1; return 0; }
   TRY(hipSetDevice(c->device));
-  ncclUniqueId id;
-  memcpy(&id, id128, sizeof(id));
+  ncclUniqueId id, idg;
+  memcpy(&id, id256, sizeof(id));
+  memcpy(&idg, (const char*)id256 + 128, sizeof(idg));
   TRYN(ncclCommInitRank(&c->comm, world, id, rank));
+  TRYN(ncclCommInitRank(&c->comm_g, world, idg, rank));
   TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   for (int i = 0; i < 8; ++i) TRY(hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming));
   TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));

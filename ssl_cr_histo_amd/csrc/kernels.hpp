@@ -23,6 +23,8 @@ using PackArgs = sslcr_pack_desc;
 // conv_igemm.hip
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st);
 int conv_tile_bp(const ConvArgs& a);
+const char* conv_kernel_name(int dtype, const ConvArgs& a);
+const char* wgrad_kernel_name(int dtype, const WgradArgs& a);
 int conv_partials_rows(const ConvArgs& a);
 // conv_halo.hip
 int conv_halo_tw(int dtype, const ConvArgs& a);

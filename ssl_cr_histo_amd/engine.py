@@ -32,6 +32,7 @@ _ENGINE_SIGS = {
     "sslcr_destroy": (C.c_int, [C.c_void_p]),
     "sslcr_profile": (C.c_int, [C.c_void_p, C.c_int]),
     "sslcr_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+    "sslcr_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "sslcr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "sslcr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "sslcr_net_create": (C.c_int, [C.c_void_p, C.POINTER(SslcrNetDesc), C.POINTER(C.c_void_p)]),
@@ -247,13 +248,19 @@ class Engine:
         """broadcast_bytes(bytes_or_None) -> bytes : host-side broadcast of the 128-byte RCCL id from rank 0."""
         if world == 1:
             return
-        idbuf = (C.c_char * 128)()
+        idbuf = (C.c_char * 256)()
         if rank == 0:
             L.check(L.lib().sslcr_comm_unique_id(idbuf))
         raw = broadcast_bytes(bytes(idbuf) if rank == 0 else None)
-        idbuf = (C.c_char * 128).from_buffer_copy(raw)
+        idbuf = (C.c_char * 256).from_buffer_copy(raw)
         L.check(L.lib().sslcr_comm_init(self.handle, idbuf, rank, world))
         self.rank, self.world = rank, world
+
+    def _reduce_losses(self, losses):
+        """logging only: each rank's (loss, loss_x, loss_u) is already scaled by 1/global-count and #correct is a count,
+        so the SUM over ranks is the global value (the data-path collectives are issued by the engine itself)."""
+        if self.world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(losses)
 
     # ------------------------------------------------------------------ measurement
     def profile(self, enable):
@@ -264,6 +271,16 @@ class Engine:
         out = (C.c_double * 4)()
         L.check(L.lib().sslcr_profile_read(self.handle, which, out))
         return dict(launches=int(out[0]), ms=out[1], flops=out[2], bytes=out[3])
+
+    def profile_table(self):
+        """per kernel instance: [dict(name, launches, ms, flops, bytes)], sorted by total time."""
+        buf = C.create_string_buffer(1 << 16)
+        L.check(L.lib().sslcr_profile_dump(self.handle, buf, len(buf)))
+        rows = []
+        for line in buf.value.decode().splitlines():
+            name, n, ms, fl, by = line.rsplit("|", 4)
+            rows.append(dict(name=name, launches=int(float(n)), ms=float(ms), flops=float(fl), bytes=float(by)))
+        return sorted(rows, key=lambda r: -r["ms"])
 
     # ------------------------------------------------------------------ binding
     def as_input(self, x):
@@ -320,6 +337,7 @@ class Engine:
                       int(nx_global or nx * self.world), int(nu_global or nu * self.world), feats.data_ptr(),
                       logits.data_ptr(), logits_t.data_ptr(), losses.data_ptr(), int(backward))
         L.check(L.lib().sslcr_step_ssl_cr(teacher.handle, student.handle, C.byref(d), L.stream_ptr()))
+        self._reduce_losses(losses)
         student._live_inputs = (xs, u_w, tf, ti)
         student._note_buffers_changed()
         return dict(losses=losses, feats=feats, logits=logits, logits_t=logits_t)
@@ -343,6 +361,7 @@ class Engine:
                     None if ti is None else ti.data_ptr(), int(n_global or n * self.world), feats.data_ptr(),
                     logits.data_ptr(), losses.data_ptr(), int(train), int(backward and train))
         L.check(L.lib().sslcr_step_supervised(net.handle, C.byref(d), L.stream_ptr()))
+        self._reduce_losses(losses)
         net._live_inputs = (xs, tf, ti)
         if train:
             net._note_buffers_changed()

@@ -29,6 +29,9 @@ class _Meters:
         self.rows, self.weights = [], []
 
     def add(self, losses, n):
+        # sharded runs: `losses` are already all-reduced global values, so the meter weight is the global count
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            n = n * torch.distributed.get_world_size()
         self.rows.append(losses)
         self.weights.append(n)
 
