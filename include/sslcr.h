@@ -123,6 +123,9 @@ typedef struct sslcr_bn_bwd_desc {
   double* sums;           /* [2][C], zeroed by the caller before reduce */
   void* dx; void* gout;
   size_t pixels; int C; int relu_from_x; double count;
+  const void* pool_dy;    /* optional: dy is not given directly but through maxpool3x3/2 pad 1 -- pooled gradient [N][pOH][pOW][C] ... */
+  const uint8_t* pool_argmax;   /* ... and the argmax codes recorded by sslcr_bn_relu_maxpool; x is then [N][pH][pW][C] */
+  int pH, pW, pOH, pOW;
 } sslcr_bn_bwd_desc;
 int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream);

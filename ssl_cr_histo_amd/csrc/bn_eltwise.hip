@@ -216,10 +216,12 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const PoolBwdArgs
         const size_t o = (((size_t)n * a.OH + oh) * a.OW + ow) * cols + col;
         float g[EPC];
         Elem<T>::unpack(ld16(dy + o * 16), g);
-        const uint8_t* ap = a.argmax + o * EPC;
+        uint32_t am[2];
+        if (EPC == 8) { const u32x2_t v = *reinterpret_cast<const u32x2_t*>(a.argmax + o * EPC); am[0] = v[0]; am[1] = v[1]; }
+        else { am[0] = *reinterpret_cast<const uint32_t*>(a.argmax + o * EPC); am[1] = 0; }
 #pragma unroll
         for (int e = 0; e < EPC; ++e)
-          if (ap[e] == code) acc[e] += g[e];
+          if (((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == (uint32_t)code) acc[e] += g[e];
       }
     }
     float f[EPC];
@@ -302,8 +304,40 @@ hipError_t launch_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int H
 template <typename T>
 __device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, int cb, float* g, float* xf) {
   constexpr int EPC = Elem<T>::EPC;
-  Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.dy) + i * 16), g);
   Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.x) + i * 16), xf);
+  if (a.pool_dy) {
+    // the gradient arrives through a 3x3/2 pad-1 max-pool (the stem): gather it from the <= 4 pooled windows that contain
+    // this pixel and whose recorded argmax is this pixel -- the un-pooled gradient tensor is never materialised
+    const int cols = a.C / EPC, col = (int)(i % cols);
+    size_t pix = i / cols;
+    const int w = (int)(pix % a.pW);
+    pix /= a.pW;
+    const int h = (int)(pix % a.pH), n = (int)(pix / a.pH);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh) {
+      const int oh = (h >> 1) + dh, wi_h = h - (2 * oh - 1);
+      if (oh >= a.pOH || wi_h < 0 || wi_h > 2 || (dh == 1 && ((h & 1) == 0))) continue;
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const int ow = (w >> 1) + dw, wi_w = w - (2 * ow - 1);
+        if (ow >= a.pOW || wi_w < 0 || wi_w > 2 || (dw == 1 && ((w & 1) == 0))) continue;
+        const int code = wi_h * 3 + wi_w;
+        const size_t o = (((size_t)n * a.pOH + oh) * a.pOW + ow) * cols + col;
+        float d[EPC];
+        Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.pool_dy) + o * 16), d);
+        uint32_t am[2];                              // EPC argmax codes in one 4/8-byte load
+        if (EPC == 8) { const u32x2_t v = *reinterpret_cast<const u32x2_t*>(a.pool_argmax + o * EPC); am[0] = v[0]; am[1] = v[1]; }
+        else { am[0] = *reinterpret_cast<const uint32_t*>(a.pool_argmax + o * EPC); am[1] = 0; }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          if (((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == (uint32_t)code) g[e] += d[e];
+      }
+    }
+  } else {
+    Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.dy) + i * 16), g);
+  }
   if (a.yact) {
     float ya[EPC];
     Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.yact) + i * 16), ya);

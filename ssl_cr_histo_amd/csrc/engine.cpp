@@ -603,13 +603,18 @@ int heads_backward(sslcr_net* n, const float* dlogits, int npass, int N, bool ne
 }
 
 // ---------------------------------------------------------------- backbone backward for one saved pass
+struct PoolSrc {            // gradient arriving through the stem max-pool (see sslcr_bn_bwd_desc.pool_dy)
+  const void* dy; const uint8_t* argmax; int H, W, OH, OW;
+};
+
 int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
-                void* dx, void* gout, size_t pixels, double count, hipStream_t st) {
+                void* dx, void* gout, size_t pixels, double count, hipStream_t st, const PoolSrc* pool = nullptr) {
   sslcr_ctx* c = n->ctx;
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.x = x; a.yact = yact; a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
   a.sums = c->bn_sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
+  if (pool) { a.pool_dy = pool->dy; a.pool_argmax = pool->argmax; a.pH = pool->H; a.pW = pool->W; a.pOH = pool->OH; a.pOW = pool->OW; }
   a.count = count * c->world;
   TRY(hipMemsetAsync(c->bn_sums, 0, 2 * bn.C * sizeof(double), st));
   TRY(launch_bn_bwd_reduce(c->dtype, a, st));
@@ -735,18 +740,12 @@ int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pa
   }
   if (low < 3) {
     // stem: maxpool+relu backward -> bn0 backward -> conv1 wgrad (no dgrad: the input is data)
-    PoolBwdArgs p;
-    memset(&p, 0, sizeof(p));
-    // dOut (= dP) sits in one half of the scratch: g0 takes the other half, dRaw0 then overwrites dP's half
-    // (stream order: the pool backward has consumed dP by then)
-    char* dp_half = (dOut >= Bf) ? Bf : A;
-    char* g0 = (dp_half == A) ? Bf : A;
-    char* dRaw0 = dp_half;
-    p.dy = dOut; p.argmax = ps.argmax; p.x = ps.raw0; p.scale = ps.bn[0].scale; p.shift = ps.bn[0].shift; p.dx = g0;
-    p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
-    TRY(launch_maxpool_relu_bwd(dt, p, st));
+    // dOut (= dP, the pooled gradient) sits in one half of the scratch; dRaw0 goes to the other half.  The max-pool + ReLU
+    // backward is folded into both BatchNorm-backward passes (the un-pooled gradient is never written out).
+    char* dRaw0 = (dOut >= Bf) ? A : Bf;
+    PoolSrc pool{dOut, ps.argmax, d.oh0, d.ow0, d.ph, d.pw};
     const size_t spix = (size_t)N * d.oh0 * d.ow0;
-    TRYI(bn_backward(n, n->bn0, ps.bn[0], g0, ps.raw0, nullptr, 0, dRaw0, nullptr, spix, (double)spix, st));
+    TRYI(bn_backward(n, n->bn0, ps.bn[0], nullptr, ps.raw0, nullptr, 1, dRaw0, nullptr, spix, (double)spix, st, &pool));
     if (n->rg[0]) {
       StemWgradArgs w;
       memset(&w, 0, sizeof(w));

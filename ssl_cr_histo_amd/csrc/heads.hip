@@ -62,24 +62,29 @@ hipError_t launch_linear_fwd(const float* x, const float* w, const float* b, flo
 }
 
 __global__ __launch_bounds__(256) void relu_mask_colsum_kernel(const float* dy, const float* yact, float* dym, float* db, int M, int N) {
-  // one thread per column n: masks dy by (yact>0) into dym and accumulates the column sum into db
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  // block = 64 columns x 4 row lanes over a 64-row slab: masks dy by (yact>0) into dym, column sums -> atomics into db
+  __shared__ float sm[4][64];
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int m0 = blockIdx.y * 64, m1 = min(M, m0 + 64);
   float s = 0.f;
-  for (int m = 0; m < M; ++m) {
-    float v = dy[(long)m * N + n];
-    if (yact && !(yact[(long)m * N + n] > 0.f)) v = 0.f;
-    if (dym) dym[(long)m * N + n] = v;
-    s += v;
+  if (n < N) {
+    for (int m = m0 + rl; m < m1; m += 4) {
+      float v = dy[(long)m * N + n];
+      if (yact && !(yact[(long)m * N + n] > 0.f)) v = 0.f;
+      if (dym) dym[(long)m * N + n] = v;
+      s += v;
+    }
   }
-  if (db) db[n] += s;
+  sm[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (db && rl == 0 && n < N) atomicAdd(db + n, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
 hipError_t launch_linear_bwd(const float* x, const float* w, const float* dy, const float* yact, float* dx, float* dw, float* db,
                              int M, int N, int K, int dx_accumulate, float* scratch, hipStream_t st) {
   const float* g = dy;
   if (yact || db) {
-    hipLaunchKernelGGL(relu_mask_colsum_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, dy, yact, yact ? scratch : nullptr, db, M, N);
+    hipLaunchKernelGGL(relu_mask_colsum_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, st, dy, yact, yact ? scratch : nullptr, db, M, N);
     if (yact) g = scratch;
   }
   hipError_t e = hipSuccess;

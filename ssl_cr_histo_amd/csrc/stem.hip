@@ -38,16 +38,59 @@ __device__ __forceinline__ void stem_load_halo(T* halo, const void* xv, int n, i
   }
 }
 
+// Split halo staging for the forward kernel: issue() puts the next tile's input bytes in flight (one value per role, roles
+// fixed per thread), commit() converts and writes them into the OTHER LDS halo buffer after the current tile's MFMAs --
+// the HBM latency of the planar uint8 gather hides under compute instead of sitting between two barriers.
+constexpr int STEM_NEL = (3 * HR * HC + 255) / 256;     // 10 values per thread
+template <bool INF32>
+__device__ __forceinline__ void stem_issue(float (&pv)[STEM_NEL], const int (&role)[STEM_NEL], const void* xv, int n, int H, int W,
+                                           int hi0, int wi0) {
+#pragma unroll
+  for (int i = 0; i < STEM_NEL; ++i) {
+    float v = 0.f;
+    if (role[i] >= 0) {
+      const int c = role[i] >> 20, rr = (role[i] >> 10) & 1023, cc = role[i] & 1023;
+      const int h = hi0 + rr, w = wi0 + cc;
+      if (h >= 0 && w >= 0 && h < H && w < W) {
+        const size_t o = ((size_t)(n * 3 + c) * H + h) * W + w;
+        v = INF32 ? reinterpret_cast<const float*>(xv)[o] : (float)reinterpret_cast<const uint8_t*>(xv)[o];
+      }
+    }
+    pv[i] = v;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void stem_commit(T* halo, const float (&pv)[STEM_NEL], const int (&role)[STEM_NEL]) {
+#pragma unroll
+  for (int i = 0; i < STEM_NEL; ++i)
+    if (role[i] >= 0) {
+      const int c = role[i] >> 20, rr = (role[i] >> 10) & 1023, cc = role[i] & 1023;
+      Elem<T>::st(halo + (rr * HC + cc) * 4 + c, pv[i]);
+    }
+}
+
 template <typename T, bool INF32>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int tiles_h, int tiles_w, int ntiles) {
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int WROW = 224 * sizeof(T) + 16;     // padded weight row: odd number of 16-byte slots
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* w_lds = smem;
-  T* halo = reinterpret_cast<T*>(smem + 64 * WROW);
+  T* halo0 = reinterpret_cast<T*>(smem + 64 * WROW);     // two halo buffers of HR*HC*4 elements
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
+  int role[STEM_NEL];
+#pragma unroll
+  for (int i = 0; i < STEM_NEL; ++i) {
+    const int idx = tid + 256 * i;
+    if (idx < 3 * HR * HC) {
+      const int c = idx / (HR * HC), rem = idx - c * (HR * HC);
+      role[i] = (c << 20) | ((rem / HC) << 10) | (rem % HC);
+    } else {
+      role[i] = -1;
+    }
+  }
+  float pv[STEM_NEL];
   // stage the packed weights [64][224] once
   {
     const char* wg = reinterpret_cast<const char*>(a.w);
@@ -56,8 +99,17 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
       const int k = i / CH, c = i - k * CH;
       st16(w_lds + k * WROW + c * 16, ld16(wg + (size_t)i * 16));
     }
-    for (int i = tid; i < HR * HC * 4; i += 256) Elem<T>::st(halo + i, 0.f);
+    for (int i = tid; i < 2 * HR * HC * 4; i += 256) Elem<T>::st(halo0 + i, 0.f);
   }
+  __syncthreads();
+  int cur = 0;
+  if ((int)blockIdx.x < ntiles) {
+    const int t0 = blockIdx.x;
+    const int n = t0 / (tiles_h * tiles_w), rem = t0 - n * tiles_h * tiles_w;
+    stem_issue<INF32>(pv, role, a.x, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
+    stem_commit<T>(halo0, pv, role);
+  }
+  __syncthreads();
   float s1[16], s2[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
@@ -69,9 +121,12 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
     const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
     const int th = rem / tiles_w, tw = rem - th * tiles_w;
     const int ho0 = th * TH, wo0 = tw * TW;
-    __syncthreads();
-    stem_load_halo<T, INF32>(halo, a.x, n, a.H, a.W, 2 * ho0 - 3, 2 * wo0 - 3);
-    __syncthreads();
+    const T* halo = halo0 + cur * (HR * HC * 4);
+    const int nxt = tile + gridDim.x;
+    if (nxt < ntiles) {
+      const int nn = nxt / (tiles_h * tiles_w), nrem = nxt - nn * tiles_h * tiles_w;
+      stem_issue<INF32>(pv, role, a.x, nn, a.H, a.W, 2 * (nrem / tiles_w) * TH - 3, 2 * (nrem % tiles_w) * TW - 3);
+    }
 
     f32x4_t acc[4][2];
 #pragma unroll
@@ -141,6 +196,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
         for (int q = 0; q < 16 / EPC; ++q) st16(yp + q * 16, Elem<T>::pack(v + q * EPC));
       }
     }
+    if (nxt < ntiles) stem_commit<T>(halo0 + (cur ^ 1) * (HR * HC * 4), pv, role);
+    __syncthreads();
+    cur ^= 1;
   }
   if (a.stats) {
 #pragma unroll
@@ -157,7 +215,7 @@ template <typename T, bool INF32>
 static hipError_t launch_stem_t(const StemArgs& a, hipStream_t st) {
   const int th = cdiv(a.OH, TH), tw = cdiv(a.OW, TW);
   const int ntiles = a.N * th * tw;
-  const size_t lds = 64 * (224 * sizeof(T) + 16) + HR * HC * 4 * sizeof(T);
+  const size_t lds = 64 * (224 * sizeof(T) + 16) + 2 * HR * HC * 4 * sizeof(T);
   auto kern = stem_fwd_kernel<T, INF32>;
   static bool attr_done = false;
   if (!attr_done) {

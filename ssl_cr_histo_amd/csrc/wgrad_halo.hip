@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
   constexpr int HL = (HP * CPR + 255) / 256;    // halo staging loads per thread
   constexpr int YBUF = 128 * RB, HBUF = HP * RB;
   constexpr int BUF = YBUF + HBUF;
-  constexpr int NBUF = BF ? 2 : 1;              // fp32 parity mode: single-buffered (LDS capacity)
+  constexpr int NBUF = (BF && TW == 16) ? 2 : 1;   // 8-wide tiles (84 KiB double-buffered) and fp32: single buffer so two workgroups fit a CU
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -211,7 +211,7 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   if (splits < 1) splits = 1;
   const int tps = cdiv(ntiles, splits);
   splits = cdiv(ntiles, tps);
-  const size_t lds = (size_t)(BF ? 2 : 1) * (128 + HP) * 64 * sizeof(T);
+  const size_t lds = (size_t)((BF && TW == 16) ? 2 : 1) * (128 + HP) * 64 * sizeof(T);
   auto kern = wgrad3x3_halo_kernel<T, TW>;
   static bool attr_done = false;
   if (!attr_done) {

@@ -186,16 +186,24 @@ def avgpool_bwd(dy, shape, dtype):
     return dx
 
 
-def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, want_g=False, count=None):
+def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, want_g=False, count=None, pool=None):
     """-> (dx, sums[2,C] fp64, g|None)."""
-    _chk(dy, x, scale, shift, mean, invstd, yact)
+    _chk(x, scale, shift, mean, invstd, yact)
+    if dy is not None:
+        _chk(dy)
     Cn = x.shape[-1]
     pixels = x.numel() // Cn
     sums = torch.zeros((2, Cn), dtype=torch.float64, device=x.device)
     dx = torch.empty_like(x)
     g = torch.empty_like(x) if want_g else None
     d = L.BnBwdDesc(L.ptr(dy), L.ptr(x), L.ptr(yact), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(sums),
-                    L.ptr(dx), L.ptr(g), pixels, Cn, int(relu_from_x), float(count if count is not None else pixels))
+                    L.ptr(dx), L.ptr(g), pixels, Cn, int(relu_from_x), float(count if count is not None else pixels),
+                    None, None, 0, 0, 0, 0)
+    if pool is not None:          # pool = (pooled_dy [N,OH,OW,C], argmax u8): dy arrives through the stem max-pool
+        pdy, pam = pool
+        _chk(pdy, pam)
+        d.pool_dy, d.pool_argmax = L.ptr(pdy), L.ptr(pam)
+        d.pH, d.pW, d.pOH, d.pOW = x.shape[1], x.shape[2], pdy.shape[1], pdy.shape[2]
     L.check(L.lib().sslcr_bn_bwd_reduce(_dt(x), d, L.stream_ptr()))
     L.check(L.lib().sslcr_bn_bwd_apply(_dt(x), d, L.stream_ptr()))
     return dx, sums, g

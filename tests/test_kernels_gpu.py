@@ -254,6 +254,11 @@ def test_bn_forward_chain(dtype):
         gact = act.grad * (act > 0)
         dx = K.maxpool_relu_bwd(to_dev(R.nhwc(dyp), dtype), am, raw, sc, sh)
         close(dx, R.nhwc(gact), 3e-4, "maxpool+relu bwd")
+        # the engine's stem form: max-pool + ReLU backward folded into the BatchNorm backward passes
+        dx_a, sums_a, _ = K.bn_bwd(dx, raw, sc, sh, mean, invstd)
+        dx_b, sums_b, _ = K.bn_bwd(None, raw, sc, sh, mean, invstd, relu_from_x=True, pool=(to_dev(R.nhwc(dyp), dtype), am))
+        close(dx_b, dx_a, 1e-5, "bn bwd through pool")
+        close(sums_b, sums_a, 1e-6, "bn bwd sums through pool")
     dap = K.avgpool_bwd(ap, tuple(pooled.shape), dtype)
     close(dap, (ap / (pooled.shape[1] * pooled.shape[2]))[:, None, None, :].expand(pooled.shape), 1e-2 if dtype else 1e-6, "avgpool bwd")
 
