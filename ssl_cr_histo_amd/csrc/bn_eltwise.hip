@@ -315,25 +315,31 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, int cb, f
     const int h = (int)(pix % a.pH), n = (int)(pix / a.pH);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+    // all four candidate windows are loaded UNCONDITIONALLY (clamped addresses) so the loads go out back to back; the
+    // window is then kept or dropped by a select -- no divergent branches around memory operations
+    u32x4_t dv[4];
+    uint32_t am[4][2];
+    bool ok[4];
+    int code[4];
 #pragma unroll
-    for (int dh = 0; dh < 2; ++dh) {
-      const int oh = (h >> 1) + dh, wi_h = h - (2 * oh - 1);
-      if (oh >= a.pOH || wi_h < 0 || wi_h > 2 || (dh == 1 && ((h & 1) == 0))) continue;
+    for (int k = 0; k < 4; ++k) {
+      const int dh = k >> 1, dw = k & 1;
+      const int oh = (h >> 1) + dh, ow = (w >> 1) + dw;
+      ok[k] = (dh == 0 || (h & 1)) && (dw == 0 || (w & 1)) && oh < a.pOH && ow < a.pOW;
+      code[k] = (h - (2 * oh - 1)) * 3 + (w - (2 * ow - 1));
+      const int ohc = oh < a.pOH ? oh : a.pOH - 1, owc = ow < a.pOW ? ow : a.pOW - 1;
+      const size_t o = (((size_t)n * a.pOH + ohc) * a.pOW + owc) * cols + col;
+      dv[k] = ld16(reinterpret_cast<const char*>(a.pool_dy) + o * 16);
+      if (EPC == 8) { const u32x2_t v = *reinterpret_cast<const u32x2_t*>(a.pool_argmax + o * EPC); am[k][0] = v[0]; am[k][1] = v[1]; }
+      else { am[k][0] = *reinterpret_cast<const uint32_t*>(a.pool_argmax + o * EPC); am[k][1] = 0; }
+    }
 #pragma unroll
-      for (int dw = 0; dw < 2; ++dw) {
-        const int ow = (w >> 1) + dw, wi_w = w - (2 * ow - 1);
-        if (ow >= a.pOW || wi_w < 0 || wi_w > 2 || (dw == 1 && ((w & 1) == 0))) continue;
-        const int code = wi_h * 3 + wi_w;
-        const size_t o = (((size_t)n * a.pOH + oh) * a.pOW + ow) * cols + col;
-        float d[EPC];
-        Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.pool_dy) + o * 16), d);
-        uint32_t am[2];                              // EPC argmax codes in one 4/8-byte load
-        if (EPC == 8) { const u32x2_t v = *reinterpret_cast<const u32x2_t*>(a.pool_argmax + o * EPC); am[0] = v[0]; am[1] = v[1]; }
-        else { am[0] = *reinterpret_cast<const uint32_t*>(a.pool_argmax + o * EPC); am[1] = 0; }
+    for (int k = 0; k < 4; ++k) {
+      float d[EPC];
+      Elem<T>::unpack(dv[k], d);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e)
-          if (((am[e >> 2] >> (8 * (e & 3))) & 0xffu) == (uint32_t)code) g[e] += d[e];
-      }
+      for (int e = 0; e < EPC; ++e)
+        if (ok[k] && ((am[k][e >> 2] >> (8 * (e & 3))) & 0xffu) == (uint32_t)code[k]) g[e] += d[e];
     }
   } else {
     Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.dy) + i * 16), g);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
     for (int c = tid; c < a.C; c += NT) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
 
   const int chunk = tid & 7;
-  int src_off[NLD], dst_off[NLD];
+  int src_off[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int hp = (tid >> 3) + (NT / 8) * i;
@@ -72,9 +72,8 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
       const int hr = rem / HWD, hc = rem - hr * HWD;
       const int h = h0 - 1 + hr, w = w0 - 1 + hc;
       src_off[i] = (h >= 0 && w >= 0 && h < a.H && w < a.W) ? ((n0 + ni) * a.H + h) * a.W + w : -1;
-      dst_off[i] = hp * 128 + ((chunk ^ (hp & 7)) << 4);
     } else {
-      src_off[i] = -2; dst_off[i] = 0;
+      src_off[i] = -2;
     }
   }
   const char* xg = reinterpret_cast<const char*>(a.x);
@@ -112,7 +111,8 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
         }
         v = Elem<T>::pack(f);
       }
-      st16(s_halo + dst_off[i], v);
+      const int hp = (tid >> 3) + (NT / 8) * i;
+      st16(s_halo + hp * 128 + ((chunk ^ (hp & 7)) << 4), v);
     }
   };
   // weights of one (slab, tap): rows k0 .. k0+BKO-1, 128 B each; thread -> (row = tid>>3 (+64), chunk)
@@ -128,6 +128,21 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
     for (int i = 0; i < WLD; ++i) {
       const int row = wperm<TK>((tid >> 3) + (NT / 8) * i);
       st16(s_w + buf * WBUF + row * 128 + ((chunk ^ (row & 7)) << 4), wreg[i]);
+    }
+  };
+
+  auto load_w_to = [&](u32x4_t (&dst)[WLD], int slab, int tap) {
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+      const int row = (tid >> 3) + (NT / 8) * i;
+      dst[i] = ld16(wg + (((size_t)(k0 + row) * 9 + tap) * a.C + slab * CE + chunk * EPC) * sizeof(T));
+    }
+  };
+  auto store_w_from = [&](const u32x4_t (&src)[WLD], int buf) {
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) {
+      const int row = wperm<TK>((tid >> 3) + (NT / 8) * i);
+      st16(s_w + buf * WBUF + row * 128 + ((chunk ^ (row & 7)) << 4), src[i]);
     }
   };
 
@@ -151,11 +166,23 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
 #pragma unroll
     for (int p = 0; p < TP; ++p) acc[t][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  // Weight pipeline: the tap computed now sits in LDS, the NEXT tap waits in registers (wnxt) and the one after that is in
+  // flight (wreg) -- an L2 round trip gets two tap-times (~2x512 MFMA cycles per wave) instead of one to land.
+  // Two register sets alternate by tap parity (static indices in the unrolled tap loop; no register copies, which would
+  // force a wait on the load in flight); nine taps per slab is odd, so the sets are swapped once per slab boundary.
+  u32x4_t wset[2][WLD];
+  const int jtot = nslabs * 9;
   if (xform) __syncthreads();
   load_halo(0);
   load_w(0, 0);
   store_halo(0);
   store_w(0);
+  constexpr bool DEEP = ONE;     // 2-tap-ahead prefetch only where registers allow it (multi-slab configs spill with it)
+  if (DEEP) {
+    load_w(0, 1);                                // jtot >= 9
+#pragma unroll
+    for (int i = 0; i < WLD; ++i) wset[0][i] = wreg[i];
+  }
   __syncthreads();
 
   int wb = 0;
@@ -164,9 +191,17 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
     if (more) load_halo(slab + 1);            // in flight during the nine taps of this slab
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const bool wnext = tap < 8 || more;
-      if (wnext) {
-        if (tap < 8) load_w(slab, tap + 1); else load_w(slab + 1, 0);
+      const int j = slab * 9 + tap;
+      const bool wnext = tap < 8 || more;        // tap j+1 exists (held in wnxt)
+      const bool wnext2 = j + 2 < jtot;          // tap j+2 exists: put it in flight now
+      u32x4_t (&held)[WLD] = wset[DEEP ? (tap & 1) : 0];          // tap j+1 (DEEP: loaded one tap ago)
+      u32x4_t (&flight)[WLD] = wset[DEEP ? ((tap & 1) ^ 1) : 0];  // DEEP: tap j+2 goes in flight now
+      if (DEEP) {
+        if (wnext2) {
+          if (tap < 7) load_w_to(flight, slab, tap + 2); else load_w_to(flight, slab + 1, tap - 7);
+        }
+      } else if (wnext) {
+        if (tap < 8) load_w_to(held, slab, tap + 1); else load_w_to(held, slab + 1, 0);
       }
       const int r = tap / 3, s = tap - 3 * r;
       const int toff = r * HWD + s;
@@ -191,9 +226,13 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
         __syncthreads();                      // every wave is done with this slab's halo
         store_halo(slab + 1);
       }
-      if (wnext) store_w(wb ^ 1);
+      if (wnext) store_w_from(held, wb ^ 1);
       __syncthreads();
       wb ^= 1;
+    }
+    if (DEEP && more) {      // after 9 taps the next tap's weights sit in wset[1]: make them wset[0] again
+#pragma unroll
+      for (int i = 0; i < WLD; ++i) { const u32x4_t t = wset[0][i]; wset[0][i] = wset[1][i]; wset[1][i] = t; }
     }
   }
 
