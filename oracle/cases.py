@@ -34,6 +34,9 @@ CASES = {
                        lambda_u=1.0, opt="sgd"),
     "cam_cr_f0": dict(script="cam_cr", hw=64, b=2, mu=2, nb=2, modules=0, classes=2, lr=5e-4, wd=1e-4,
                       lambda_u=0.5, opt="sgd"),
+    # eval_Kather_SSL_CR.train/validate: 9-class CE + hard pseudo-label CE, Adam (:527); 256 is hard-coded (:68)
+    "kather_cr_f0": dict(script="kather_cr", hw=256, b=1, mu=2, nb=2, modules=0, classes=9, lr=1e-4, wd=1e-4,
+                         lambda_u=1.0, opt="adam"),
     # pretrain_BreastPathQ.train/validate: RSP 6-way CE, SGD-Nesterov lr .01 + Lookahead(5,.5) (:245-247)
     "rsp": dict(script="rsp", hw=64, b=4, nb=2, classes=6, lr=0.01, wd=1e-4, opt="sgd"),
     # eval_Camelyon_SSL.train: supervised CE (student only), SGD-Nesterov (:371)
@@ -57,6 +60,18 @@ def labeled_batches_cls(case, seed0, label):
     c = CASES[case]
     return [(u8(seed0 + i, (c["b"], 3, 3, c["hw"], c["hw"])),
              torch.full((c["b"], 3), label, dtype=torch.int64)) for i in range(c["nb"])]
+
+
+def labeled_batches_kather(case, seed0=1000):
+    """Kather labeled loader: (x u8 [b,3,3,H,W], y int64 [b,3] in 0..8)."""
+    c = CASES[case]
+    return [(u8(seed0 + i, (c["b"], 3, 3, c["hw"], c["hw"])), ints(seed0 + 50 + i, (c["b"], 3), c["classes"]))
+            for i in range(c["nb"])]
+
+
+def val_batches_kather(case, seed0=4000):
+    c = CASES[case]
+    return [(u8(seed0 + i, (2, 3, c["hw"], c["hw"])), ints(seed0 + 50 + i, (2,), c["classes"])) for i in range(2)]
 
 
 def unlabeled_batches(case, seed0=2000):

@@ -66,6 +66,26 @@ def cam_cr_validate(ps, bs, val_tumor, val_normal, faithful=True):
     return losses.avg, acc.avg
 
 
+def kather_cr_train(ps, bs, pt, bt, opt, labeled, unlabeled, lambda_u, faithful=True):
+    """eval_Kather_SSL_CR.py:37-127 -> (loss, loss_x, loss_u, acc)."""
+    losses, losses_x, losses_u, acc = (S.AverageMeter() for _ in range(4))
+    for (x, y), (u_w, u_s) in zip(labeled, unlabeled):
+        x = x.float().reshape(-1, 3, 256, 256)                               # :68
+        y = y.long().reshape(-1)
+        r = S.ssl_cr_step("ce", ps, bs, pt, bt, opt, x, y, u_w.float(), u_s.float(), lambda_u, faithful)
+        n = x.shape[0]
+        losses_x.update(r["loss_x"], n); losses_u.update(r["loss_u"], n); losses.update(r["loss"], n); acc.update(r["acc"], n)
+    return losses.avg, losses_x.avg, losses_u.avg, acc.avg
+
+
+def kather_cr_validate(ps, bs, val_loader, faithful=True):
+    losses, acc = S.AverageMeter(), S.AverageMeter()
+    for x, y in val_loader:
+        r = S.supervised_step("ce", ps, bs, None, x.float(), y.long(), faithful, train=False)
+        losses.update(r["loss"], y.size(0)); acc.update(r["acc"], y.size(0))
+    return losses.avg, acc.avg
+
+
 def rsp_epoch(p, b, opt, loader, tile, train=True):
     losses, acc = S.AverageMeter(), S.AverageMeter()
     feats, targets = [], []

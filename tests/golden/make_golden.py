@@ -150,6 +150,23 @@ def gen_cam_cr(name, out):
     out[f"{name}/val"] = np.array(val, dtype=np.float64)
 
 
+def gen_kather_cr(name, out):
+    c = C.CASES[name]
+    m = importlib.import_module("eval_Kather_SSL_CR")
+    mt, ct = build("finetune", "finetune", 9, rand_stats=True)
+    ms, cs = build("finetune", "finetune", 9, rand_stats=True)
+    freeze(mt, 64)
+    freeze(ms, c["modules"])
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())),
+                           lr=c["lr"], betas=(0.9, 0.999), weight_decay=c["wd"])
+    ret = m.train(args_ns(lambda_u=c["lambda_u"]), mt, ms, ct, cs, C.labeled_batches_kather(name),
+                  C.unlabeled_batches(name), opt, 1)
+    out[f"{name}/ret"] = np.array(ret, dtype=np.float64)
+    snapshot(name, ms, cs, out)
+    val = m.validate(args_ns(), ms, cs, C.val_batches_kather(name), 1)
+    out[f"{name}/val"] = np.array(val, dtype=np.float64)
+
+
 def gen_rsp(name, out):
     c = C.CASES[name]
     m = importlib.import_module("pretrain_BreastPathQ")
@@ -232,7 +249,7 @@ def gen_stages(out):
 
 def main():
     gens = {"bpq_cr_f60": gen_bpq_cr, "bpq_cr_f0": gen_bpq_cr, "cam_cr_f60": gen_cam_cr, "cam_cr_f0": gen_cam_cr,
-            "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup}
+            "kather_cr_f0": gen_kather_cr, "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup}
     only = sys.argv[1:]
     for name, fn in gens.items():
         if only and name not in only:
@@ -240,8 +257,7 @@ def main():
         out = {}
         fn(name, out)
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
-        print("wrote", name, {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if "/ret" in k or "/val" in k},
-              out[f"{name}/ret"])
+        print("wrote", name, out[f"{name}/ret"])
     if not only or "stages" in only:
         out = {}
         gen_stages(out)

@@ -150,6 +150,31 @@ def test_cam_cr_epoch_vs_reference(name, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_kather_cr_epoch_vs_reference(dtype):
+    from ssl_cr_histo_amd import steps
+    _engine(dtype)
+    name = "kather_cr_f0"
+    c = C.CASES[name]
+    g = load_golden(name)
+    mt, ct = build("finetune", "finetune", 9, True)
+    ms, cs = build("finetune", "finetune", 9, True)
+    freeze(mt, 64)
+    freeze(ms, c["modules"])
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())), lr=c["lr"],
+                           betas=(0.9, 0.999), weight_decay=c["wd"])
+    ret = steps.kather_cr_train(ns(lambda_u=c["lambda_u"]), mt, ms, ct, cs, C.labeled_batches_kather(name),
+                                C.unlabeled_batches(name), opt, 1)
+    ts, tf, tp = TOLS[dtype]
+    for i in range(3):
+        assert abs(ret[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i]), (i, ret[i], g[f"{name}/ret"][i])
+    if dtype == "fp32":
+        assert ret[3] == g[f"{name}/ret"][3]
+        check_snapshot(g, name, state_of(ms, cs), tp)
+    val = steps.kather_cr_validate(ns(), ms, cs, C.val_batches_kather(name), 1)
+    assert abs(val[0] - g[f"{name}/val"][0]) <= (5e-3 if dtype == "fp32" else 1e-1) * g[f"{name}/val"][0]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_rsp_epoch_and_lookahead_vs_reference(dtype):
     from ssl_cr_histo_amd import steps
     from ssl_cr_histo_amd.lookahead import Lookahead

@@ -64,6 +64,21 @@ def test_cam_cr(name, faithful):
     assert val[1] == g[f"{name}/val"][1]
 
 
+def test_kather_cr():
+    name = "kather_cr_f0"
+    c = C.CASES[name]
+    g = load_golden(name)
+    ps, bs, pt, bt = _student_teacher(9, c["modules"])
+    opt = S.Adam(ps.values(), c["lr"], (0.9, 0.999), 1e-8, c["wd"])
+    ret = E.kather_cr_train(ps, bs, pt, bt, opt, C.labeled_batches_kather(name), C.unlabeled_batches(name), c["lambda_u"])
+    for i in range(3):
+        assert abs(ret[i] - g[f"{name}/ret"][i]) <= RT * abs(g[f"{name}/ret"][i])
+    assert ret[3] == g[f"{name}/ret"][3]
+    check_snapshot(g, name, snapshot_dict(ps, bs), RT)
+    val = E.kather_cr_validate(ps, bs, C.val_batches_kather(name))
+    assert abs(val[0] - g[f"{name}/val"][0]) <= RT * g[f"{name}/val"][0] and val[1] == g[f"{name}/val"][1]
+
+
 def test_rsp_and_lookahead():
     name = "rsp"
     c = C.CASES[name]
