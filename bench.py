@@ -227,6 +227,14 @@ def main():
                                "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
                                "algorithmic_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 2),
                                "time_share_of_step": round(d["ms"] / (ms_per_step * nprof), 3)}
+            # HBM traffic of this kernel comes from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), which
+            # cannot run inside this process: report the committed measurement of one instance beside its algorithmic bytes
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_layer2_conv_wgrad.json")
+            if os.path.exists(pmc) and "conv3x3_halo256_kernel<unsigned short, 16, 128" in d["name"]:
+                out["roofline"]["traffic_pmc"] = {
+                    "instance": "N=640 32x32 C128->K128 3x3/1 forward (train prologue + stats)", "fetch_size_x2_mb": 203.6,
+                    "write_size_mb": 174.1, "traffic_mb": 377.7, "algorithmic_mb": 335.9, "ratio": 1.12,
+                    "source": "profiles/r01_pmc_layer2_conv_wgrad.md"}
             out["conv_kernels"] = [{"kernel": r["name"], "launches_per_step": r["launches"] // nprof,
                                     "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
                                     "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),

@@ -41,6 +41,10 @@ __device__ __forceinline__ void stem_load_halo(T* halo, const void* xv, int n, i
 // Split halo staging for the forward kernel: issue() puts the next tile's input bytes in flight (one value per role, roles
 // fixed per thread), commit() converts and writes them into the OTHER LDS halo buffer after the current tile's MFMAs --
 // the HBM latency of the planar uint8 gather hides under compute instead of sitting between two barriers.
+// kout owned by MFMA tile t, fragment row group q (= lane>>2 for the A fragment, lane>>4 for the accumulator), element j:
+// a lane's 16 channels form two 8-channel runs 32 channels apart, so the four lane groups of one pixel write contiguous
+// 64-byte segments (16 consecutive channels per lane would leave every 16-byte store half of a 32-byte stride)
+#define STEM_CH(t, q, j) ((((t) >> 1) * 32) + ((q) * 8) + (((t) & 1) * 4) + (j))
 constexpr int STEM_NEL = (3 * HR * HC + 255) / 256;     // 10 values per thread
 template <bool INF32>
 __device__ __forceinline__ void stem_issue(float (&pv)[STEM_NEL], const int (&role)[STEM_NEL], const void* xv, int n, int H, int W,
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
   for (int j = 0; j < 16; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
   float bias[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) bias[j] = a.bias ? a.bias[g * 16 + j] : 0.f;
+  for (int j = 0; j < 16; ++j) bias[j] = a.bias ? a.bias[STEM_CH(j >> 2, g, j & 3)] : 0.f;
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
         u32x4_t af[4], bfr[2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const int k = (li >> 2) * 16 + t * 4 + (li & 3);
+          const int k = STEM_CH(t, li >> 2, li & 3);
           af[t] = ld16(w_lds + k * WROW + (r * 8 + 2 * g) * 4 * sizeof(T));
         }
 #pragma unroll
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
           float av[4], bv[2];
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
-            const int k = (li >> 2) * 16 + t * 4 + (li & 3);
+            const int k = STEM_CH(t, li >> 2, li & 3);
             av[t] = *reinterpret_cast<const float*>(w_lds + k * WROW + ((r * 8 + s) * 4 + g) * 4);
           }
 #pragma unroll
@@ -190,10 +194,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
           v[t * 4 + j] = a.relu ? fmaxf(o, 0.f) : o;
         }
       if (valid) {
-        char* yp = reinterpret_cast<char*>(a.y) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64 + g * 16) * sizeof(T);
+        char* yp = reinterpret_cast<char*>(a.y) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64) * sizeof(T);
         constexpr int EPC = Elem<T>::EPC;
 #pragma unroll
-        for (int q = 0; q < 16 / EPC; ++q) st16(yp + q * 16, Elem<T>::pack(v + q * EPC));
+        for (int q = 0; q < 16 / EPC; ++q)         // v[q*EPC ..] are EPC consecutive channels starting at STEM_CH(.)
+          st16(yp + STEM_CH((q * EPC) >> 2, g, 0) * sizeof(T), Elem<T>::pack(v + q * EPC));
       }
     }
     if (nxt < ntiles) stem_commit<T>(halo0 + (cur ^ 1) * (HR * HC * 4), pv, role);
@@ -204,9 +209,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
 #pragma unroll
     for (int j = 0; j < 16; ++j) { s1[j] = row16_sum(s1[j]); s2[j] = row16_sum(s2[j]); }
     if (li == 0) {
-      float* sp = a.stats + ((size_t)(blockIdx.x * 4 + wave) * 2) * 64 + g * 16;
+      float* sp = a.stats + ((size_t)(blockIdx.x * 4 + wave) * 2) * 64;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) { sp[j] = s1[j]; sp[64 + j] = s2[j]; }
+      for (int j = 0; j < 16; ++j) { sp[STEM_CH(j >> 2, g, j & 3)] = s1[j]; sp[64 + STEM_CH(j >> 2, g, j & 3)] = s2[j]; }
     }
   }
 }

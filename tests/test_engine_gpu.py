@@ -305,3 +305,45 @@ def test_deepcopy_teacher_and_state_dict_roundtrip():
     steps.teacher_refresh(mt2, ct2, ms, cs, 0.0)
     mt2.eval()
     assert torch.equal(mt2(x), f0)
+
+
+def test_checkpoint_resume_roundtrip():
+    """reference-style checkpoint dict ('model', 'classifier', 'optimizer' + `module.` prefix, eval_Camelyon_SSL_CR.py:575-590)
+    saved after step 1 and resumed into fresh modules continues exactly like the uninterrupted run."""
+    import io
+    from ssl_cr_histo_amd.net import strip_module_prefix
+    eng = _engine("fp32")
+    hw, nx, nu = 64, 4, 4
+    batches = [(C.u8(9000 + i, (nx, 3, hw, hw)), C.ints(9010 + i, (nx,), 2), C.u8(9020 + i, (nu, 3, hw, hw)),
+                C.u8(9030 + i, (nu, 3, hw, hw))) for i in range(2)]
+
+    def make():
+        mt, ct = build("finetune", "finetune", 2, True)
+        ms, cs = build("finetune", "finetune", 2, True)
+        freeze(mt, 64)
+        mt.eval(); ms.train()
+        opt = torch.optim.Adam(list(ms.parameters()) + list(cs.parameters()), lr=1e-3, weight_decay=1e-4)
+        return mt, ct, ms, cs, opt
+
+    def step(mt, ct, ms, cs, opt, b):
+        te, st = eng.bind(mt, ct), eng.bind(ms, cs)
+        r = eng.step_ssl_cr(te, st, "ce", b[0], b[1], b[2], b[3], 1.0)
+        st.optimizer_step(opt)
+        return r["losses"].cpu()
+
+    mt, ct, ms, cs, opt = make()
+    step(mt, ct, ms, cs, opt, batches[0])
+    buf = io.BytesIO()
+    torch.save({"model": {"module." + k: v for k, v in ms.state_dict().items()},
+                "classifier": {"module." + k: v for k, v in cs.state_dict().items()}, "optimizer": opt.state_dict(), "epoch": 1}, buf)
+    l2 = step(mt, ct, ms, cs, opt, batches[1])
+    buf.seek(0)
+    ck = torch.load(buf, map_location=DEV, weights_only=False)
+    mt2, ct2, ms2, cs2, opt2 = make()
+    ms2.load_state_dict(strip_module_prefix(ck["model"]))
+    cs2.load_state_dict(strip_module_prefix(ck["classifier"]))
+    opt2.load_state_dict(ck["optimizer"])
+    l2b = step(mt2, ct2, ms2, cs2, opt2, batches[1])
+    assert torch.allclose(l2, l2b, rtol=1e-5, atol=1e-7), (l2, l2b)
+    for (k, a), (_, b) in zip(ms.state_dict().items(), ms2.state_dict().items()):
+        assert rel_err(b.float().cpu(), a.float().cpu()) < 2e-5, k
