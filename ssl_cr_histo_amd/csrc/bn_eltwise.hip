@@ -96,15 +96,22 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
   const char* x = reinterpret_cast<const char*>(a.x);
   const char* r = reinterpret_cast<const char*>(a.res);
   char* y = reinterpret_cast<char*>(a.y);
+  // grid stride is a multiple of cols: the thread's EPC channels (and their constants) are fixed for the whole loop
+  const int cb = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % cols) * EPC;
+  float sc[EPC], sh[EPC], rsc[EPC], rsh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    sc[e] = a.scale[cb + e]; sh[e] = a.shift[cb + e];
+    rsc[e] = a.rscale ? a.rscale[cb + e] : 1.f; rsh[e] = a.rscale ? a.rshift[cb + e] : 0.f;
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cb = (int)(i % cols) * EPC;
     float f[EPC], g[EPC];
     Elem<T>::unpack(ld16(x + i * 16), f);
     if (r) Elem<T>::unpack(ld16(r + i * 16), g);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
-      float v = fmaf(f[e], a.scale[cb + e], a.shift[cb + e]);
-      if (r) v += a.rscale ? fmaf(g[e], a.rscale[cb + e], a.rshift[cb + e]) : g[e];
+      float v = fmaf(f[e], sc[e], sh[e]);
+      if (r) v += fmaf(g[e], rsc[e], rsh[e]);
       f[e] = a.relu ? fmaxf(v, 0.f) : v;
     }
     st16(y + i * 16, Elem<T>::pack(f));
@@ -133,6 +140,12 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs 
   const size_t total = (size_t)a.N * a.OH * a.OW * cols;
   const char* x = reinterpret_cast<const char*>(a.x);
   char* y = reinterpret_cast<char*>(a.y);
+  float psc[EPC], psh[EPC];                  // fixed channels per thread (grid stride is a multiple of cols)
+  {
+    const int cb0 = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % cols) * EPC;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { psc[e] = a.scale[cb0 + e]; psh[e] = a.shift[cb0 + e]; }
+  }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int col = (int)(i % cols);
     size_t pix = i / cols;
@@ -140,7 +153,6 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs 
     pix /= a.OW;
     const int oh = (int)(pix % a.OH);
     const int n = (int)(pix / a.OH);
-    const int cb = col * EPC;
     float best[EPC];
     int arg[EPC];
 #pragma unroll
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs 
       Elem<T>::unpack(ld16(x + (((size_t)n * a.H + h) * a.W + w) * a.C * sizeof(T) + (size_t)col * 16), f);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
-        float v = fmaxf(fmaf(f[e], a.scale[cb + e], a.shift[cb + e]), 0.f);
+        float v = fmaxf(fmaf(f[e], psc[e], psh[e]), 0.f);
         if (v > best[e]) { best[e] = v; arg[e] = wi; }
       }
     }
@@ -302,7 +314,7 @@ hipError_t launch_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int H
 
 // ------------------------------------------------------------------ BatchNorm backward
 template <typename T>
-__device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, int cb, float* g, float* xf) {
+__device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, const float* rsc, const float* rsh, float* g, float* xf) {
   constexpr int EPC = Elem<T>::EPC;
   Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.x) + i * 16), xf);
   if (a.pool_dy) {
@@ -353,7 +365,7 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, int cb, f
   } else if (a.relu_from_x) {
 #pragma unroll
     for (int e = 0; e < EPC; ++e)
-      if (!(fmaf(xf[e], a.scale[cb + e], a.shift[cb + e]) > 0.f)) g[e] = 0.f;
+      if (!(fmaf(xf[e], rsc[e], rsh[e]) > 0.f)) g[e] = 0.f;
   }
 }
 
@@ -365,13 +377,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   const int rpp = 256 / cols;                 // pixel rows per pass
   const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
   const int cb = col * EPC;
-  float s0[EPC], s1[EPC], mean[EPC];
+  // per-channel constants of this thread's EPC channels live in registers for the whole grid-stride loop (re-reading them per
+  // 16-byte chunk costs more L1 traffic than the tensor data itself)
+  float s0[EPC], s1[EPC], mean[EPC], rsc[EPC], rsh[EPC];
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) { s0[e] = 0.f; s1[e] = 0.f; mean[e] = a.mean[cb + e]; }
+  for (int e = 0; e < EPC; ++e) { s0[e] = 0.f; s1[e] = 0.f; mean[e] = a.mean[cb + e]; rsc[e] = a.scale[cb + e]; rsh[e] = a.shift[cb + e]; }
   if (rl < rpp) {
     for (size_t p = (size_t)blockIdx.x * rpp + rl; p < a.pixels; p += (size_t)gridDim.x * rpp) {
       float g[EPC], xf[EPC];
-      bn_bwd_g<T>(a, p * cols + col, cb, g, xf);
+      bn_bwd_g<T>(a, p * cols + col, rsc, rsh, g, xf);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) { s0[e] += g[e]; s1[e] = fmaf(g[e], xf[e] - mean[e], s1[e]); }
     }
@@ -395,17 +409,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   const int cols = a.C / EPC;
   const size_t total = a.pixels * cols;
   const float invM = (float)(1.0 / a.count);
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int cb = (int)(i % cols) * EPC;
-    float g[EPC], xf[EPC], d[EPC];
-    bn_bwd_g<T>(a, i, cb, g, xf);
+  // the grid stride (gridDim.x*256) is a multiple of cols, so a thread always works on the same EPC channels:
+  // dx = cA*g + cB*x + cC with cA = scale, cB = -scale*invstd^2*mean(g*(x-mu)), cC = -scale*mean(g) - cB*mu
+  const int cb = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % cols) * EPC;
+  float cA[EPC], cB[EPC], cC[EPC], rsc[EPC], rsh[EPC];
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      const int c = cb + e;
-      const float is = a.invstd[c];
-      const float m0 = (float)a.sums[c] * invM, m1 = (float)a.sums[a.C + c] * invM;
-      d[e] = a.scale[c] * (g[e] - m0 - (xf[e] - a.mean[c]) * is * is * m1);
-    }
+  for (int e = 0; e < EPC; ++e) {
+    const int c = cb + e;
+    const float is = a.invstd[c], sc = a.scale[c];
+    const float m0 = (float)a.sums[c] * invM, m1 = (float)a.sums[a.C + c] * invM;
+    cA[e] = sc;
+    cB[e] = -sc * is * is * m1;
+    cC[e] = -sc * m0 - cB[e] * a.mean[c];
+    rsc[e] = sc; rsh[e] = a.shift[c];
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float g[EPC], xf[EPC], d[EPC];
+    bn_bwd_g<T>(a, i, rsc, rsh, g, xf);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) d[e] = fmaf(cA[e], g[e], fmaf(cB[e], xf[e], cC[e]));
     st16(reinterpret_cast<char*>(a.dx) + i * 16, Elem<T>::pack(d));
     if (a.gout) st16(reinterpret_cast<char*>(a.gout) + i * 16, Elem<T>::pack(g));
   }

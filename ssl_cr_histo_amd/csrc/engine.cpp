@@ -102,7 +102,7 @@ struct ProfRec {
 };
 struct Profiler {               // optional HIP-event bracketing of the conv launches (bench.py roofline leg)
   bool on = false;
-  std::vector<ProfRec> rec[2];  // 0: conv_igemm (fwd + dgrad), 1: wgrad
+  std::vector<ProfRec> rec[3];  // 0: conv (fwd + dgrad), 1: wgrad, 2: bn_bwd_apply (the largest HBM-bound kernel; flops = 0)
   std::vector<hipEvent_t> pool;
   hipEvent_t get() {
     if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
@@ -619,7 +619,23 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
   TRY(hipMemsetAsync(c->bn_sums, 0, 2 * bn.C * sizeof(double), st));
   TRY(launch_bn_bwd_reduce(c->dtype, a, st));
   if (c->world > 1) TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
-  TRY(launch_bn_bwd_apply(c->dtype, a, st));
+  if (c->prof.on) {
+    ProfRec r;
+    r.e0 = c->prof.get(); r.e1 = c->prof.get();
+    r.name = c->dtype == DT_BF16 ? "sslcr::bn_bwd_apply_kernel<unsigned short>" : "sslcr::bn_bwd_apply_kernel<float>";
+    r.flops = 0.0;
+    // algorithmic bytes: read dy (or the 4x smaller pooled gradient + 1-byte argmax), x, (saved output for the ReLU mask); write dx (, g)
+    const double t = (double)pixels * bn.C * c->esz();
+    const double rd = (pool ? 0.25 * t + 0.25 * (double)pixels * bn.C : t) + t + (yact ? t : 0.0);
+    r.bytes = rd + t + (gout ? t : 0.0);
+    (void)hipEventRecord(r.e0, st);
+    hipError_t e = launch_bn_bwd_apply(c->dtype, a, st);
+    (void)hipEventRecord(r.e1, st);
+    c->prof.rec[2].push_back(r);
+    TRY(e);
+  } else {
+    TRY(launch_bn_bwd_apply(c->dtype, a, st));
+  }
   if (n->rg[bn.pg] || n->rg[bn.pb]) {
     // dgamma/dbeta: with synced BN the sums are already global -> scale so that the later grad all-reduce(sum)/world is right
     float* dg = gptr(n, bn.pg);
@@ -839,7 +855,7 @@ int sslcr_profile(sslcr_ctx* c, int enable) {
   if (!c) return fail("sslcr_profile: null");
   c->prof.on = enable != 0;
   if (enable) {
-    for (int w = 0; w < 2; ++w) {
+    for (int w = 0; w < 3; ++w) {
       for (auto& r : c->prof.rec[w]) { c->prof.pool.push_back(r.e0); c->prof.pool.push_back(r.e1); }
       c->prof.rec[w].clear();
     }
@@ -852,7 +868,7 @@ int sslcr_profile_dump(sslcr_ctx* c, char* buf, size_t n) {
   TRY(hipDeviceSynchronize());
   struct Row { const char* name; double launches, ms, flops, bytes; };
   std::vector<Row> rows;
-  for (int w = 0; w < 2; ++w)
+  for (int w = 0; w < 3; ++w)
     for (auto& r : c->prof.rec[w]) {
       float t = 0.f;
       TRY(hipEventElapsedTime(&t, r.e0, r.e1));
