@@ -42,10 +42,14 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
   constexpr int WLD = BKO * 8 / NT;          // 16-byte weight staging loads per thread per tap (1 or 2)
   constexpr int TK = BKO / (16 * WK), TP = 4;
   constexpr int HBUF = HP * 128, WBUF = BKO * 128;
+  // TPB = taps per barrier.  512-thread configs are alone on their CU (registers), so LDS is free: the weight ring holds
+  // 2 x 3 taps and the workgroup synchronises once per filter ROW instead of once per tap; a prefetched tap is written into
+  // the other half of the ring without a barrier, so an L2 round trip only ever stalls the wave that issued it.
+  constexpr int TPB = (WK == 2 && !ONE) ? 3 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_halo = smem;
   char* s_w = smem + HBUF;                    // [2][BKO][128 B]
-  float* s_scale = reinterpret_cast<float*>(smem + HBUF + 2 * WBUF);
+  float* s_scale = reinterpret_cast<float*>(smem + HBUF + 2 * TPB * WBUF);
   float* s_shift = s_scale + a.C;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,9 +178,12 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
   const int jtot = nslabs * 9;
   if (xform) __syncthreads();
   load_halo(0);
-  load_w(0, 0);
   store_halo(0);
-  store_w(0);
+#pragma unroll
+  for (int t = 0; t < TPB; ++t) {                // ring half 0 <- taps 0..TPB-1
+    load_w(0, t);
+    store_w_from(wreg, t);
+  }
   constexpr bool DEEP = ONE;     // 2-tap-ahead prefetch only where registers allow it (multi-slab configs spill with it)
   if (DEEP) {
     load_w(0, 1);                                // jtot >= 9
@@ -200,12 +207,13 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
         if (wnext2) {
           if (tap < 7) load_w_to(flight, slab, tap + 2); else load_w_to(flight, slab + 1, tap - 7);
         }
-      } else if (wnext) {
-        if (tap < 8) load_w_to(held, slab, tap + 1); else load_w_to(held, slab + 1, 0);
+      } else if (j + TPB < jtot) {                 // tap j+TPB: same ring slot, other half
+        if (tap + TPB < 9) load_w_to(held, slab, tap + TPB); else load_w_to(held, slab + 1, tap + TPB - 9);
       }
       const int r = tap / 3, s = tap - 3 * r;
       const int toff = r * HWD + s;
-      const char* wbuf = s_w + wb * WBUF;
+      const int slot = tap % TPB;
+      const char* wbuf = s_w + (wb * TPB + slot) * WBUF;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int ci = kk * 4 + g;
@@ -226,9 +234,15 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
         __syncthreads();                      // every wave is done with this slab's halo
         store_halo(slab + 1);
       }
-      if (wnext) store_w_from(held, wb ^ 1);
-      __syncthreads();
-      wb ^= 1;
+      if (DEEP) {
+        if (wnext) store_w_from(held, wb ^ 1);
+      } else if (j + TPB < jtot) {
+        store_w_from(held, (wb ^ 1) * TPB + slot);
+      }
+      if (slot == TPB - 1) {
+        __syncthreads();
+        wb ^= 1;
+      }
     }
     if (DEEP && more) {      // after 9 taps the next tap's weights sit in wset[1]: make them wset[0] again
 #pragma unroll
@@ -310,11 +324,12 @@ int conv_halo256_tiles(const ConvArgs& a, int mode) {
 template <typename T, int TW, int BKO, int WK, bool ONE>
 static hipError_t launch_q(const ConvArgs& a, hipStream_t st) {
   constexpr int HP = (256 / (TW * TW)) * (TW + 2) * (TW + 2);
-  const size_t lds = HP * 128 + 2 * BKO * 128 + 2 * a.C * sizeof(float);
+  constexpr int TPB = (WK == 2 && !ONE) ? 3 : 1;
+  const size_t lds = HP * 128 + 2 * TPB * BKO * 128 + 2 * a.C * sizeof(float);
   auto kern = conv3x3_halo256_kernel<T, TW, BKO, WK, ONE>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
