@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
       const int toff = r * HWD + s;
       const int slot = tap % TPB;
       const char* wbuf = s_w + (wb * TPB + slot) * WBUF;
-#pragma unroll
+#pragma unroll((TW == 8 && !ONE && BKO == 128) ? 1 : 2)      // the 4-image x 8x8 wide config is register-bound
       for (int kk = 0; kk < 2; ++kk) {
         const int ci = kk * 4 + g;
         u32x4_t af[TK], bfr[TP];

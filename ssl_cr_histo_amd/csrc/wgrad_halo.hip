@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
     const char* hb = yb + YBUF;
     if constexpr (BF) {
 #pragma unroll 1
-      for (int q = 0; q < 4; ++q) {              // 32-pixel MFMA depth steps of the 128-pixel tile (not unrolled: registers)
+      for (int q = 0; q < 4; ++q) {              // 32-pixel MFMA depth steps of the 128-pixel tile (unrolling it spills)
         const int p0 = q * 32 + 8 * g + (li >> 2);          // this lane's source pixels for the transpose reads
         bf16x8_t af[4];
 #pragma unroll
