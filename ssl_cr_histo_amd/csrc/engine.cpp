@@ -3,6 +3,7 @@
 // step; every kernel goes to the caller's stream.  See include/sslcr.h for the reference code each entry replaces.
 #include <rccl/rccl.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -321,7 +322,7 @@ int finalize_bn(sslcr_net* n, const BnL& bn, const float* partials, int rows, do
   a.running_mean = n->bn_rm[bn.bidx]; a.running_var = n->bn_rv[bn.bidx]; a.num_batches_tracked = n->bn_nbt[bn.bidx];
   a.momentum = 0.1f; a.eps = 1e-5f; a.replay = replay;
   a.stage = c->bn_stage;
-  if (c->world > 1) {
+  if (c->comm) {
     // global-batch statistics: reduce rows -> [2][C] sums, all-reduce, finalize from the sums
     BnFinalizeArgs r = a;
     r.sums_out = c->bn_sums;
@@ -618,7 +619,7 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
   a.count = count * c->world;
   TRY(hipMemsetAsync(c->bn_sums, 0, 2 * bn.C * sizeof(double), st));
   TRY(launch_bn_bwd_reduce(c->dtype, a, st));
-  if (c->world > 1) TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
+  if (c->comm) TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
   if (c->prof.on) {
     ProfRec r;
     r.e0 = c->prof.get(); r.e1 = c->prof.get();
@@ -659,7 +660,7 @@ int wgrad_call(sslcr_net* n, const ConvL& L, const void* x, const void* dy, cons
 
 int launch_bucket_allreduce(sslcr_net* n, int bucket, size_t lo, size_t hi, hipStream_t st) {
   sslcr_ctx* c = n->ctx;
-  if (c->world <= 1 || hi <= lo) return 0;
+  if (!c->comm_g || hi <= lo) return 0;
   TRY(hipEventRecord(c->ev_ready[bucket], st));
   TRY(hipStreamWaitEvent(c->comm_stream, c->ev_ready[bucket], 0));
   float* g = (float*)n->grads.p + lo;
@@ -808,7 +809,7 @@ int net_backward(sslcr_net* n, const float* dlogits, hipStream_t st) {
   if (bb) {
     for (int i = npass - 1; i >= 0; --i) TRYI(backbone_backward(n, n->pass[i], n->dE[i], i == 0, st));
   }
-  if (c->world > 1) {
+  if (c->comm_g) {
     TRY(hipEventRecord(c->ev_done, c->comm_stream));
     TRY(hipStreamWaitEvent(st, c->ev_done, 0));
   }
@@ -911,7 +912,9 @@ int sslcr_comm_unique_id(void* id256) {
 
 int sslcr_comm_init(sslcr_ctx* c, const void* id256, int rank, int world) {
   if (!c || !id256 || world < 1 || rank < 0 || rank >= world) return fail("sslcr_comm_init: invalid argument");
-  if (world == 1) { c->rank = 0; c->world = 1; return 0; }
+  // world == 1 normally needs no communicator; SSLCR_COMM_SELFTEST=1 creates the two 1-rank communicators anyway so that the
+  // whole collective code path (RCCL calls, side stream, events) can be exercised on a single-GPU box (tests/test_engine_gpu.py)
+  if (world == 1 && !getenv("SSLCR_COMM_SELFTEST")) { c->rank = 0; c->world = 1; return 0; }
   TRY(hipSetDevice(c->device));
   ncclUniqueId id, idg;
   memcpy(&id, id256, sizeof(id));

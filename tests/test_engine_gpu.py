@@ -5,6 +5,7 @@ fp32 engine mode carries the north-star bound (1e-3 relative on logits/loss; loo
 amplify error such as post-Adam parameters).  bf16 mode is held to measured, looser bounds against the same goldens.
 """
 import copy
+import os
 import types
 
 import numpy as np
@@ -347,3 +348,45 @@ def test_checkpoint_resume_roundtrip():
     assert torch.allclose(l2, l2b, rtol=1e-5, atol=1e-7), (l2, l2b)
     for (k, a), (_, b) in zip(ms.state_dict().items(), ms2.state_dict().items()):
         assert rel_err(b.float().cpu(), a.float().cpu()) < 2e-5, k
+
+
+def test_collective_code_path_selftest_world1():
+    """SSLCR_COMM_SELFTEST=1 builds the engine's two RCCL communicators with ONE rank and routes a full fine-tune step through
+    every collective call site (synced-BN all-reduces forward and backward, bucketed gradient all-reduce on the side stream,
+    event joins).  With one rank the collectives are identities, so the step must reproduce the plain path."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from oracle import cases as C
+from ssl_cr_histo_amd import engine as E
+import test_engine_gpu as T
+eng = E.set_engine(E.Engine("cuda:0", "fp32"))
+if os.environ.get("SSLCR_COMM_SELFTEST"):
+    eng.init_comm(0, 1, lambda b: b)
+mt, ct = T.build("finetune", "finetune", 2, True); ms, cs = T.build("finetune", "finetune", 2, True)
+T.freeze(mt, 64); mt.eval(); ms.train()
+te, st = eng.bind(mt, ct), eng.bind(ms, cs)
+x, u_w, u_s = C.u8(1, (4, 3, 64, 64)), C.u8(2, (4, 3, 64, 64)), C.u8(3, (4, 3, 64, 64))
+y = C.ints(4, (4,), 2)
+opt = torch.optim.SGD(list(ms.parameters()) + list(cs.parameters()), lr=1e-2, momentum=0.9, nesterov=True)
+for _ in range(2):
+    r = eng.step_ssl_cr(te, st, "ce", x, y, u_w, u_s, 1.0); st.optimizer_step(opt)
+torch.cuda.synchronize()
+print("RESULT", " ".join(f"{v:.7e}" for v in r["losses"].cpu().tolist()), f"{float(dict(ms.named_parameters())['model.conv1.weight'].double().norm()):.9e}",
+      f"{float(dict(ms.named_parameters())['model.layer4.1.bn2.weight'].double().sum()):.9e}")
+'''
+    outs = []
+    for flag in ("", "1"):
+        env = dict(os.environ)
+        env.pop("SSLCR_COMM_SELFTEST", None)
+        if flag:
+            env["SSLCR_COMM_SELFTEST"] = "1"
+        p = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
+        outs.append([float(v) for v in line.split()[1:]])
+    for a, b in zip(*outs):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), outs
