@@ -58,6 +58,34 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
   const char* xg = reinterpret_cast<const char*>(a.x);
   const char* dyg = reinterpret_cast<const char*>(a.dy);
 
+  // Staging roles are fixed per thread: pixel offsets relative to the tile origin and "touches the top/bottom/left/right
+  // halo ring" flags are computed ONCE, so a tile costs one add per load and a mask test instead of div/mod chains (the
+  // kernel is VALU-issue bound: 735 VALU per 144 MFMAs before this).
+  int rel_y[YL], rel_h[HL];
+  static_assert(HL <= 16, "edge mask holds 16 halo entries");
+  unsigned long long edge = 0;               // 4 bits per halo entry: top, bottom, left, right
+  unsigned hvalid = 0;                       // entry exists (hp < HP)
+#pragma unroll
+  for (int i = 0; i < YL; ++i) {
+    const int p = prow + (256 / CPR) * i;
+    const int ni = p / (TH * TW), rem = p - ni * (TH * TW);
+    const int ph = rem / TW, pw = rem - ph * TW;
+    rel_y[i] = (ni * a.H + ph) * a.W + pw;
+  }
+#pragma unroll
+  for (int i = 0; i < HL; ++i) {
+    const int hp = prow + (256 / CPR) * i;
+    rel_h[i] = 0;
+    if (hp < HP) {
+      const int ni = hp / (HH * HWD), rem = hp - ni * (HH * HWD);
+      const int hr = rem / HWD, hc = rem - hr * HWD;
+      rel_h[i] = (ni * a.H + hr - 1) * a.W + hc - 1;
+      hvalid |= 1u << i;
+      edge |= (unsigned long long)((hr == 0) | ((hr == HH - 1) << 1) | ((hc == 0) << 2) | ((hc == HWD - 1) << 3)) << (4 * i);
+    }
+  }
+  const size_t ybase = ((size_t)k0 + chunk * EPC) * sizeof(T), xbase = ((size_t)c0 + chunk * EPC) * sizeof(T);
+
   u32x4_t yreg[YL], hreg[HL];
   unsigned hin = 0;
   auto load_regs = [&](int tile) {
@@ -66,28 +94,21 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
     const int th_i = t % tiles_h;
     const int n0 = (t / tiles_h) * NI;
     const int h0 = th_i * TH, w0 = tw_i * TW;
+    const int origin = (n0 * a.H + h0) * a.W + w0;                    // pixel index of the tile's (0,0)
+    // which halo rings fall outside the image for this tile (uniform)
+    const unsigned long long out =
+        (unsigned long long)((h0 == 0) | ((h0 + TH >= a.H) << 1) | ((w0 == 0) << 2) | ((w0 + TW >= a.W) << 3)) * 0x1111111111111111ull;
 #pragma unroll
-    for (int i = 0; i < YL; ++i) {
-      const int p = prow + (256 / CPR) * i;                 // pixel of the tile
-      const int ni = p / (TH * TW), rem = p - ni * (TH * TW);
-      const int ph = rem / TW, pw = rem - ph * TW;
-      const size_t pix = ((size_t)(n0 + ni) * a.H + h0 + ph) * a.W + w0 + pw;
-      yreg[i] = ld16(dyg + (pix * a.K + k0 + chunk * EPC) * sizeof(T));
-    }
-    hin = 0;
+    for (int i = 0; i < YL; ++i)
+      yreg[i] = ld16(dyg + (size_t)(origin + rel_y[i]) * a.K * sizeof(T) + ybase);
+    hin = hvalid;
+    const unsigned long long bad = edge & out;                                   // entry i is padding iff any of its 4 bits is set
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-      const int hp = prow + (256 / CPR) * i;
       u32x4_t v = {0u, 0u, 0u, 0u};
-      if (hp < HP) {
-        const int ni = hp / (HH * HWD), rem = hp - ni * (HH * HWD);
-        const int hr = rem / HWD, hc = rem - hr * HWD;
-        const int h = h0 - 1 + hr, w = w0 - 1 + hc;
-        if (h >= 0 && w >= 0 && h < a.H && w < a.W) {
-          v = ld16(xg + ((((size_t)(n0 + ni) * a.H + h) * a.W + w) * a.C + c0 + chunk * EPC) * sizeof(T));
-          hin |= 1u << i;
-        }
-      }
+      const bool ok = ((hvalid >> i) & 1u) && !((bad >> (4 * i)) & 0xfull);
+      if (ok) v = ld16(xg + (size_t)(origin + rel_h[i]) * a.C * sizeof(T) + xbase);
+      else hin &= ~(1u << i);
       hreg[i] = v;
     }
   };
