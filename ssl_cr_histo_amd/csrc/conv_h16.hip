@@ -1,0 +1,425 @@
+// 3x3 / stride 1 / pad 1 NHWC convolution on 16x16-pixel tiles: persistent, DMA-fed form of the LDS-halo kernel
+// (ResNet18 layer1-3 block convs forward and their dgrads through tap-flipped packs; conv_halo256.hip keeps the
+// 4-image x 8x8 layer4 shape and is the fallback).
+//
+// What the previous form lost, measured by ablation on the layer2 shape (N=640, 32x32, 128->128: 220 us, MFMA-only ~95 us):
+// removing the MFMAs left 137 us, the halo loads 47 us, the weight loads 50 us, the epilogue 52 us, the barriers 31 us --
+// i.e. the parts ran back to back instead of under each other.  The ISA showed why: (1) the compiler sank every weight
+// prefetch down to its LDS store, so each tap waited a full L2 round trip; (2) s_waitcnt vmcnt counts IN ORDER, so the first
+// wait on a (young, short) weight load also waited for the (older, long) HBM halo loads and for the epilogue stores of the
+// previous tile; (3) ~55 VGPRs held per-tap LDS addresses, leaving no room to double-buffer fragments, so the wave ran
+// ds_read -> wait -> 4 MFMA -> ds_read ...
+//
+// This kernel is built around those three facts:
+//   * weights go global -> LDS by DMA (global_load_lds_dwordx4, no registers, no ds_write): a whole ring half (3 taps) is
+//     issued right after the barrier that frees it and waited for once, just before the barrier that publishes it, three
+//     taps later.  The lane picks its SOURCE chunk so that the linear DMA placement is the swizzled, fragment-ordered tile.
+//   * the halo of the next stage is requested after the first weight wait of a stage, so the only vmcnt waits in the
+//     stream are >= 3 taps (~3000 clk) behind every load and store they cover; BatchNorm+ReLU of the producer is applied to
+//     the halo IN REGISTERS under the MFMAs of the last three taps, and only six ds_write_b128 sit between the two barriers
+//     of a stage boundary.
+//   * the halo rows are pitched 24 pixels (18 used) so that the XOR swizzle key (pixel & 7) depends on the lane and the
+//     filter column only: all nine taps, four pixel groups and TK weight tiles are immediate offsets on 6 + 2 address
+//     registers, and fragments are double-buffered in the registers this frees.
+//   * persistent workgroups (one per CU) walk items (tile, kout block) b, b+G, ...: the epilogue's stores drain under the
+//     next item's taps and the next item's first halo is already in LDS when the last tap retires.
+#include "kernels.hpp"
+
+namespace sslcr {
+
+template <typename T> struct MmaH;
+template <> struct MmaH<bf16_t> {
+  __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct MmaH<float> {
+  __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+// fp32 -> storage type, 8 (bf16) / 4 (fp32) values per 16-byte chunk.  bf16 uses the hardware RNE pack (v_cvt_pk_bf16_f32):
+// this kernel's epilogue is VALU-exposed, one instruction per pair instead of ~7 matters here.
+template <typename T> struct PackH {
+  __device__ static __forceinline__ u32x4_t run(const float* f) { return Elem<T>::pack(f); }
+};
+template <> struct PackH<bf16_t> {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  __device__ static __forceinline__ u32x4_t run(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * i], f[2 * i + 1]}, bf16x2_t));
+    return v;
+  }
+};
+
+// inverse of wperm<TK> (common.hpp): LDS row -> kout row of the block
+template <int TK>
+__device__ __forceinline__ int wperm_inv(int rr) {
+  constexpr int B = 16 * TK;
+  const int blk = rr / B, x = rr - blk * B;
+  const int t = x >> 4, q = (x >> 2) & 3, j = x & 3;
+  return blk * B + q * (4 * TK) + t * 4 + j;
+}
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#define SSLCR_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0f70) /* vmcnt(0), lgkmcnt/expcnt untouched */
+
+// XF: the producer's BatchNorm(+ReLU) is applied to the input on its way into LDS (a.in_scale != nullptr)
+template <typename T, int BKO, int WK, bool XF>
+__global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items) {
+  constexpr int NT = 256 * WK;
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int CE = 8 * EPC;                 // channels per 128-byte slab
+  constexpr int TW = 16, TH = 16, HH = 18, HWD = 18, PITCH = 24;
+  constexpr int HP = HH * HWD;                // 324 staged halo pixels
+  constexpr int NLD = (HP * 8 + NT - 1) / NT; // 16-byte halo loads per thread per stage
+  constexpr int WLD = BKO * 8 / NT;           // DMA instructions per thread per tap
+  constexpr int TK = BKO / (16 * WK), TP = 4;
+  constexpr int HBUF = HH * PITCH * 128, WBUF = BKO * 128, TPB = 3;
+  static_assert(NLD <= 16 && WLD >= 1, "staging shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* s_halo = smem;
+  char* s_w = smem + HBUF;                    // [2][TPB][BKO][128 B]
+  float* s_scale = reinterpret_cast<float*>(smem + HBUF + 2 * TPB * WBUF);
+  float* s_shift = s_scale + a.C;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int wp = wave & 3, wk = wave >> 2;
+  const int tiles_w = a.W / TW, tiles_h = a.H / TH;
+  if (XF)
+    for (int c = tid; c < a.C; c += NT) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
+  const float relu_lo = a.in_relu ? 0.f : -__builtin_inff();
+
+  // XCD-aware walk: blocks land on XCD (blockIdx % 8); each XCD takes a contiguous run of tiles per round so that
+  // neighbouring tiles' shared halo rows hit the same L2.
+  const int G = gridDim.x;
+  const int first = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+  if (first >= n_items) return;
+
+  // ---- per-thread staging roles, fixed for the whole walk
+  const int chunk = tid & 7;
+  int rel[NLD], st_off[NLD];
+  unsigned long long edge = 0;                // 4 bits per entry: on the top / bottom / left / right halo ring
+  unsigned hvalid = 0;
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int sp = (tid >> 3) + (NT / 8) * i;
+    rel[i] = 0; st_off[i] = 0;
+    if (sp < HP) {
+      const int hr = sp / HWD, hc = sp - hr * HWD;
+      rel[i] = (hr - 1) * a.W + hc - 1;
+      const int hp = hr * PITCH + hc;
+      st_off[i] = hp * 128 + ((chunk ^ (hp & 7)) << 4);
+      hvalid |= 1u << i;
+      edge |= (unsigned long long)((hr == 0) | ((hr == HH - 1) << 1) | ((hc == 0) << 2) | ((hc == HWD - 1) << 3)) << (4 * i);
+    }
+  }
+  // weight DMA: instruction i of this wave fills LDS rows [i*(NT/8) + wave*8, +8) of a tap; lane -> (row, 16-byte slot)
+  int wsrc[WLD];
+#pragma unroll
+  for (int i = 0; i < WLD; ++i) {
+    const int rr = i * (NT / 8) + wave * 8 + (lane >> 3);
+    const int krow = wperm_inv<TK>(rr);
+    const int c16 = (lane & 7) ^ (rr & 7);
+    wsrc[i] = (int)(((size_t)krow * 9 * a.C + c16 * EPC) * sizeof(T));
+  }
+  // fragment addresses: everything but these 8 registers is an immediate offset
+  int Bb[3][2], Ab[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ci = kk * 4 + g;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) Bb[s][kk] = ((wp * 4) * PITCH + li + s) * 128 + ((ci ^ ((li + s) & 7)) << 4);
+    Ab[kk] = (wk * (BKO / WK) + li) * 128 + ((ci ^ (li & 7)) << 4);
+  }
+  const char* xg = reinterpret_cast<const char*>(a.x) + (size_t)chunk * EPC * sizeof(T);
+  const char* wg = reinterpret_cast<const char*>(a.w);
+  const int nslabs = a.C / CE;
+
+  struct Geo { int origin, k0, tile, n0, h0, w0; unsigned long long out; };
+  auto geom = [&](int item) {
+    Geo q;
+    const int kbi = item / tiles_total;
+    q.tile = item - kbi * tiles_total;
+    q.k0 = kbi * BKO;
+    int t = q.tile;
+    const int tw_i = t % tiles_w; t /= tiles_w;
+    const int th_i = t % tiles_h;
+    q.n0 = t / tiles_h;
+    q.h0 = th_i * TH; q.w0 = tw_i * TW;
+    q.origin = (q.n0 * a.H + q.h0) * a.W + q.w0;
+    q.out = (unsigned long long)((q.h0 == 0) | ((q.h0 + TH >= a.H) << 1) | ((q.w0 == 0) << 2) | ((q.w0 + TW >= a.W) << 3)) *
+            0x1111111111111111ull;
+    return q;
+  };
+
+  u32x4_t hreg[NLD];
+  unsigned hin = 0;                           // hreg[i] holds image data (not zero padding)
+  // branch-free: padding entries load the tile origin (a valid address) and are zeroed when staged
+  auto load_halo = [&](const Geo& q, int slab) {
+    const unsigned long long bad = edge & q.out;
+    hin = 0;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const bool ok = ((hvalid >> i) & 1u) && !((bad >> (4 * i)) & 0xfull);
+      const int idx = q.origin + (ok ? rel[i] : 0);
+      hreg[i] = ld16(xg + ((size_t)idx * a.C + slab * CE) * sizeof(T));
+      hin |= (ok ? 1u : 0u) << i;
+    }
+  };
+  float sc[EPC], sh[EPC];
+  auto load_affine = [&](int slab) {
+    if (XF) {
+      const int cb = slab * CE + chunk * EPC;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { sc[e] = s_scale[cb + e]; sh[e] = s_shift[cb + e]; }
+    }
+  };
+  auto xform_one = [&](int i) {                // hreg[i] -> what LDS must hold
+    u32x4_t v = hreg[i];
+    if (XF) {
+      float f[EPC];
+      Elem<T>::unpack(v, f);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), relu_lo);
+      v = PackH<T>::run(f);
+    }
+    const bool ok = (hin >> i) & 1u;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0u;
+    hreg[i] = v;
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      if ((hvalid >> i) & 1u) st16(s_halo + st_off[i], hreg[i]);
+  };
+  // DMA the three taps tap0..tap0+2 of (kout block k0, slab) into ring half `half`
+  auto dma_w = [&](int k0, int slab, int tap0, int half) {
+#pragma unroll
+    for (int tt = 0; tt < TPB; ++tt) {
+      const char* src = wg + ((size_t)k0 * 9 * a.C + (size_t)(tap0 + tt) * a.C + slab * CE) * sizeof(T);
+#pragma unroll
+      for (int i = 0; i < WLD; ++i) {
+        char* dst = s_w + (half * TPB + tt) * WBUF + (i * (NT / 8) + wave * 8) * 128;
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + wsrc[i]), (lptr_t)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  f32x4_t acc[TK][TP];
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int p = 0; p < TP; ++p) acc[t][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragments are double-buffered across the WHOLE walk: step i (tap i/2, 64-byte half kk = i&1) requests the fragments of
+  // step i+1 before it runs its 16*TK/4 MFMAs, across barriers too
+  u32x4_t A[2][TK], B[2][TP];
+  auto frags = [&](int buf, int step, const char* ringg) {     // ringg: the ring half holding tap (step>>1)'s group
+    const int tap = step >> 1, kk = step & 1;
+    const int r = tap / 3, s = tap - 3 * r;
+#pragma unroll
+    for (int t = 0; t < TK; ++t) A[buf][t] = ld16(ringg + Ab[kk] + s * WBUF + t * 2048);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) B[buf][p] = ld16(s_halo + Bb[s][kk] + (p + r) * (PITCH * 128));
+  };
+
+  // ---- pipeline fill: halo of (first item, slab 0) and ring half 0 <- taps 0..2
+  Geo cur = geom(first);
+  dma_w(cur.k0, 0, 0, 0);
+  load_halo(cur, 0);
+  if (XF) __syncthreads();
+  load_affine(0);
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) xform_one(i);
+  store_halo();
+  SSLCR_WAIT_VM0();
+  __syncthreads();
+  frags(0, 0, s_w);
+
+  char* yg = reinterpret_cast<char*>(a.y);
+  const char* rg = reinterpret_cast<const char*>(a.residual);
+  int wb = 0, item = first, slab = 0;
+  for (;;) {
+    // the stage after this one: next slab of this tile, or slab 0 of the next item (the last stage of the walk re-requests
+    // itself: branch-free, and nobody reads what it stages)
+    const bool last = slab + 1 == nslabs;
+    const bool done = last && item + G >= n_items;
+    const int nslab = last ? 0 : slab + 1;
+    const Geo nxt = (last && !done) ? geom(item + G) : cur;
+    const char* ring0 = s_w + wb * (TPB * WBUF);          // taps 0-2 and 6-8 of this stage
+    const char* ring1 = s_w + (wb ^ 1) * (TPB * WBUF);    // taps 3-5, and taps 0-2 of the next stage
+
+    // Schedule of a stage (18 steps, 3 tap groups G0 G1 G2 on alternating ring halves):
+    //   group start : DMA the NEXT group's three taps into the half the previous group just released
+    //   mid group   : vmcnt(0) + barrier P  -> the next group's weights are published one and a half taps before they are
+    //                 needed, so the fragment prefetch of its first step does not wait behind a barrier
+    //   group end   : barrier F            -> everybody is done with this group's half; it may be overwritten
+    //   mid G1      : request the next stage's halo (HBM), mid G2 it has landed (same vmcnt(0)); steps 15-17 transform it
+    //   stage end   : barrier, six ds_write_b128, barrier -- the only place the fragment pipeline drains
+    dma_w(cur.k0, slab, 3, wb ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      // the scheduler fences keep "request the next fragments, then run this step's MFMAs (with the halo transform under
+      // them)" in that order; left alone the compiler serialises read -> wait -> MFMA, sinks prefetches down to their
+      // first use and moves the VALU work into the barrier-to-barrier section of the stage boundary
+      if (i < 17) frags((i + 1) & 1, i + 1, (((i + 1) / 6) & 1) ? ring1 : ring0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TK; ++t)
+#pragma unroll
+        for (int p = 0; p < TP; ++p) MmaH<T>::run(A[i & 1][t], B[i & 1][p], acc[t][p]);
+      if (i >= 15) {
+#pragma unroll
+        for (int j = (i - 15); j < NLD; j += 3) xform_one(j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i % 6 == 2) {
+        SSLCR_WAIT_VM0();
+        __syncthreads();                                  // P
+        if (i == 8) {
+          load_halo(nxt, nslab);
+          load_affine(nslab);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i == 5 || i == 11) {
+        __syncthreads();                                  // F
+        if (i == 5) dma_w(cur.k0, slab, 6, wb); else dma_w(nxt.k0, nslab, 0, wb ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                          // every wave is done with this stage's halo
+    store_halo();
+    __syncthreads();
+    wb ^= 1;
+    frags(0, 0, s_w + wb * (TPB * WBUF));      // first fragments of the next stage: in flight under the epilogue
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (last) {
+      // ---------------- epilogue of the finished item; its stores drain under the next item's taps
+      const int kb = cur.k0 + wk * (BKO / WK) + g * (4 * TK);
+      float bias[4 * TK];
+#pragma unroll
+      for (int j = 0; j < 4 * TK; ++j) bias[j] = a.bias ? a.bias[kb + j] : 0.f;
+#pragma unroll
+      for (int p = 0; p < TP; ++p) {
+        const int h = cur.h0 + wp * 4 + p, w = cur.w0 + li;
+        const size_t off = ((((size_t)cur.n0 * a.H + h) * a.W + w) * a.K + kb) * sizeof(T);
+        float v[4 * TK];
+#pragma unroll
+        for (int t = 0; t < TK; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[t * 4 + j] = acc[t][p][j] + bias[t * 4 + j];
+#pragma unroll
+        for (int q = 0; q < 4 * TK / EPC; ++q) {
+          float* vq = v + q * EPC;
+          if (rg) {
+            float rr[EPC];
+            Elem<T>::unpack(ld16(rg + off + q * 16), rr);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
+          }
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) vq[e] = fmaxf(vq[e], 0.f);
+          }
+          st16(yg + off + q * 16, PackH<T>::run(vq));
+        }
+      }
+      if (a.stats) {
+        float s1[4 * TK], s2[4 * TK];
+#pragma unroll
+        for (int t = 0; t < TK; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+            for (int p = 0; p < TP; ++p) { float q = acc[t][p][j]; x1 += q; x2 = fmaf(q, q, x2); }
+            s1[t * 4 + j] = row16_sum(x1);
+            s2[t * 4 + j] = row16_sum(x2);
+          }
+        if (li == 0) {
+          float* sp = a.stats + ((size_t)(cur.tile * 4 + wp) * 2) * a.K + kb;
+#pragma unroll
+          for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
+        }
+      }
+      if (done) break;
+#pragma unroll
+      for (int t = 0; t < TK; ++t)
+#pragma unroll
+        for (int p = 0; p < TP; ++p) acc[t][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      item += G;
+      cur = nxt;
+    }
+    slab = nslab;
+  }
+}
+
+static int device_cus() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
+bool conv_h16_ok(int dtype, const ConvArgs& a) {
+  return conv_halo256_mode(dtype, a) == 16 && conv_halo256_mode(DT_BF16, a) == 16;
+}
+
+template <typename T, int BKO, int WK, bool XF>
+static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
+  const size_t lds = 18 * 24 * 128 + 2 * 3 * BKO * 128 + 2 * a.C * sizeof(float);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  auto kern = conv3x3_h16_kernel<T, BKO, WK, XF>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int tiles = a.N * (a.H / 16) * (a.W / 16);
+  const int n_items = tiles * (a.K / BKO);
+  const int grid = n_items < device_cus() ? n_items : device_cus();     // one 8-wave workgroup per CU
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WK), lds, st, a, tiles, n_items);
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_ht(const ConvArgs& a, hipStream_t st) {
+  const bool xf = a.in_scale != nullptr;
+  if (a.K % 128 == 0) return xf ? launch_h<T, 128, 2, true>(a, st) : launch_h<T, 128, 2, false>(a, st);
+  return xf ? launch_h<T, 64, 2, true>(a, st) : launch_h<T, 64, 2, false>(a, st);
+}
+
+hipError_t launch_conv_h16(int dtype, const ConvArgs& a, hipStream_t st) {
+  return dtype == DT_BF16 ? launch_ht<bf16_t>(a, st) : launch_ht<float>(a, st);
+}
+
+const char* conv_h16_name(int dtype, const ConvArgs& a) {
+  const bool bf = dtype == DT_BF16, xf = a.in_scale != nullptr;
+  if (a.K % 128 == 0) {
+    if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, true>" : "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, false>";
+    return xf ? "sslcr::conv3x3_h16_kernel<float, 128, 2, true>" : "sslcr::conv3x3_h16_kernel<float, 128, 2, false>";
+  }
+  if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false>";
+  return xf ? "sslcr::conv3x3_h16_kernel<float, 64, 2, true>" : "sslcr::conv3x3_h16_kernel<float, 64, 2, false>";
+}
+
+}  // namespace sslcr

@@ -301,6 +301,7 @@ static hipError_t launch_t(const ConvArgs& a, hipStream_t st) {
 const char* conv_kernel_name(int dtype, const ConvArgs& a) {
   const bool bf = dtype == DT_BF16;
   const bool wide = a.K % 128 == 0;
+  if (conv_h16_ok(dtype, a)) return conv_h16_name(dtype, a);
   const int q = conv_halo256_mode(dtype, a);
   if (q && conv_halo256_mode(DT_BF16, a) == q) {
     const bool one = a.C == (bf ? 64 : 32);
@@ -324,6 +325,7 @@ const char* conv_kernel_name(int dtype, const ConvArgs& a) {
 }
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
+  if (conv_h16_ok(dtype, a)) return launch_conv_h16(dtype, a, st);
   const int q = conv_halo256_mode(dtype, a);
   if (q && conv_halo256_mode(DT_BF16, a) == q) return launch_conv_halo256(dtype, a, q, st);
   const int tw = q ? 0 : conv_halo_tw(dtype, a);
