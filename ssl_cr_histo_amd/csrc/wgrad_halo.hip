@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
     if (more) load_regs(tile + 1);
     const char* yb = smem + buf * BUF;
     const char* hb = yb + YBUF;
-    if constexpr (BF) {
+    if constexpr (BF && TW == 8) {
 #pragma unroll 1
       for (int q = 0; q < 4; ++q) {              // 32-pixel MFMA depth steps of the 128-pixel tile (unrolling it spills)
         const int p0 = q * 32 + 8 * g + (li >> 2);          // this lane's source pixels for the transpose reads
@@ -176,6 +176,41 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
 #pragma unroll
           for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t4], bfrag, acc[t][t4], 0, 0, 0);
         }
+      }
+    } else if constexpr (BF) {
+      // 32-pixel MFMA depth steps of the 128-pixel tile.  The B fragment of the NEXT tap (or of tap 0 of the next depth
+      // step) is requested before the four MFMAs of this tap; scheduler fences keep it that way (left alone the compiler
+      // emits read -> wait -> 4 MFMA per tap and the matrix pipe idles for an LDS round trip nine times per step).
+      const int coff = (16 * wave + (li & 3) * 4) * 2;
+      bf16x8_t bfr[2];
+      auto bfrag_of = [&](int q, int t) {
+        const int p0 = q * 32 + 8 * g + (li >> 2);
+        const int toff = (t / 3) * HWD + (t % 3);
+        return tr_pair(hb + (hpix(p0) + toff) * RB + coff, hb + (hpix(p0 + 4) + toff) * RB + coff);
+      };
+      auto qstep = [&](const int q, const int par) {       // par: which of bfr[] holds (q, tap 0)
+        const int p0 = q * 32 + 8 * g + (li >> 2);          // this lane's source pixels for the transpose reads
+        bf16x8_t af[4];
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+          const char* pa = yb + p0 * RB + (16 * t4 + (li & 3) * 4) * 2;
+          af[t4] = tr_pair(pa, pa + 4 * RB);
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          bfr[(t + 1 + par) & 1] = t < 8 ? bfrag_of(q, t + 1) : bfrag_of(q < 3 ? q + 1 : 3, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int t4 = 0; t4 < 4; ++t4)
+            acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t4], bfr[(t + par) & 1], acc[t][t4], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      bfr[0] = bfrag_of(0, 0);
+#pragma unroll 1
+      for (int q2 = 0; q2 < 2; ++q2) {           // nine taps flip the buffer parity: two depth steps per trip
+        qstep(2 * q2, 0);
+        qstep(2 * q2 + 1, 1);
       }
     } else {
 #pragma unroll 2
