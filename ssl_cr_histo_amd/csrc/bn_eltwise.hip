@@ -106,15 +106,15 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
   }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float f[EPC], g[EPC];
-    Elem<T>::unpack(ld16(x + i * 16), f);
-    if (r) Elem<T>::unpack(ld16(r + i * 16), g);
+    Elem<T>::unpack(ld16_nt(x + i * 16), f);
+    if (r) Elem<T>::unpack(ld16_nt(r + i * 16), g);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       float v = fmaf(f[e], sc[e], sh[e]);
       if (r) v += fmaf(g[e], rsc[e], rsh[e]);
       f[e] = a.relu ? fmaxf(v, 0.f) : v;
     }
-    st16(y + i * 16, Elem<T>::pack(f));
+    st16_nt(y + i * 16, Elem<T>::pack(f));
   }
 }
 
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs 
         if (v > best[e]) { best[e] = v; arg[e] = wi; }
       }
     }
-    st16(y + i * 16, Elem<T>::pack(best));
+    st16_nt(y + i * 16, Elem<T>::pack(best));
     if (a.argmax) {
       uint8_t* ap = a.argmax + i * EPC;
       if (EPC == 8) {
@@ -237,11 +237,11 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const PoolBwdArgs
       }
     }
     float f[EPC];
-    Elem<T>::unpack(ld16(x + i * 16), f);
+    Elem<T>::unpack(ld16_nt(x + i * 16), f);
 #pragma unroll
     for (int e = 0; e < EPC; ++e)
       if (!(fmaf(f[e], a.scale[cb + e], a.shift[cb + e]) > 0.f)) acc[e] = 0.f;
-    st16(dx + i * 16, Elem<T>::pack(acc));
+    st16_nt(dx + i * 16, Elem<T>::pack(acc));
   }
 }
 
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* dy, void*
     float f[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; ++e) f[e] = dy[(size_t)n * C + col * EPC + e] * inv;
-    st16(dx + i * 16, Elem<T>::pack(f));
+    st16_nt(dx + i * 16, Elem<T>::pack(f));
   }
 }
 
@@ -316,7 +316,7 @@ hipError_t launch_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int H
 template <typename T>
 __device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, const float* rsc, const float* rsh, float* g, float* xf) {
   constexpr int EPC = Elem<T>::EPC;
-  Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.x) + i * 16), xf);
+  Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.x) + i * 16), xf);
   if (a.pool_dy) {
     // the gradient arrives through a 3x3/2 pad-1 max-pool (the stem): gather it from the <= 4 pooled windows that contain
     // this pixel and whose recorded argmax is this pixel -- the un-pooled gradient tensor is never materialised
@@ -354,11 +354,11 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, const flo
         if (ok[k] && ((am[k][e >> 2] >> (8 * (e & 3))) & 0xffu) == (uint32_t)code[k]) g[e] += d[e];
     }
   } else {
-    Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.dy) + i * 16), g);
+    Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.dy) + i * 16), g);
   }
   if (a.yact) {
     float ya[EPC];
-    Elem<T>::unpack(ld16(reinterpret_cast<const char*>(a.yact) + i * 16), ya);
+    Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.yact) + i * 16), ya);
 #pragma unroll
     for (int e = 0; e < EPC; ++e)
       if (!(ya[e] > 0.f)) g[e] = 0.f;
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     bn_bwd_g<T>(a, i, rsc, rsh, g, xf);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) d[e] = fmaf(cA[e], g[e], fmaf(cB[e], xf[e], cC[e]));
-    st16(reinterpret_cast<char*>(a.dx) + i * 16, Elem<T>::pack(d));
-    if (a.gout) st16(reinterpret_cast<char*>(a.gout) + i * 16, Elem<T>::pack(g));
+    st16_nt(reinterpret_cast<char*>(a.dx) + i * 16, Elem<T>::pack(d));
+    if (a.gout) st16_nt(reinterpret_cast<char*>(a.gout) + i * 16, Elem<T>::pack(g));
   }
 }
 

@@ -79,6 +79,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __device__ __forceinline__ u32x4_t ld16(const void* p) { return *reinterpret_cast<const u32x4_t*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4_t& v) { *reinterpret_cast<u32x4_t*>(p) = v; }
+// streaming (non-temporal) forms for the read-once / write-once tensors of the HBM-bound elementwise kernels
+__device__ __forceinline__ u32x4_t ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
+__device__ __forceinline__ void st16_nt(void* p, const u32x4_t& v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p)); }
 
 // Weight tiles sit in LDS in MFMA-fragment order: kout row r = q*(4TK) + t*4 + j of a 16*TK-row block (q = fragment lane>>2,
 // t = MFMA tile, j = lane&3 -- the permutation that gives a lane 4*TK consecutive output channels) is stored at row
