@@ -61,6 +61,24 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
 };
 
+// fp32 -> storage type, 8 (bf16) / 4 (fp32) values per 16-byte chunk.  bf16 uses the hardware RNE pack (v_cvt_pk_bf16_f32):
+// for VALU-exposed epilogues (conv_h16, stem): one instruction per pair instead of ~7.  (Used selectively: as the
+// default pack it made the register-bound wgrad kernels slower.)
+template <typename T> struct PackH {
+  __device__ static __forceinline__ u32x4_t run(const float* f) { return Elem<T>::pack(f); }
+};
+template <> struct PackH<bf16_t> {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  __device__ static __forceinline__ u32x4_t run(const float* f) {
+    u32x4_t v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      v[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * i], f[2 * i + 1]}, bf16x2_t));
+    return v;
+  }
+};
+
 // ---- DPP all-reduce (sum) across the 16 lanes of a DPP row: quad xor1, quad xor2, half-mirror, mirror
 __device__ __forceinline__ float row16_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));

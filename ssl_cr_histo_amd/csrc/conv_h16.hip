@@ -41,23 +41,6 @@ template <> struct MmaH<float> {
   }
 };
 
-// fp32 -> storage type, 8 (bf16) / 4 (fp32) values per 16-byte chunk.  bf16 uses the hardware RNE pack (v_cvt_pk_bf16_f32):
-// this kernel's epilogue is VALU-exposed, one instruction per pair instead of ~7 matters here.
-template <typename T> struct PackH {
-  __device__ static __forceinline__ u32x4_t run(const float* f) { return Elem<T>::pack(f); }
-};
-template <> struct PackH<bf16_t> {
-  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  typedef float f32x2_t __attribute__((ext_vector_type(2)));
-  __device__ static __forceinline__ u32x4_t run(const float* f) {
-    u32x4_t v;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      v[i] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{f[2 * i], f[2 * i + 1]}, bf16x2_t));
-    return v;
-  }
-};
-
 // inverse of wperm<TK> (common.hpp): LDS row -> kout row of the block
 template <int TK>
 __device__ __forceinline__ int wperm_inv(int rr) {

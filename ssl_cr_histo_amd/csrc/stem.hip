@@ -73,6 +73,50 @@ __device__ __forceinline__ void stem_commit(T* halo, const float (&pv)[STEM_NEL]
     }
 }
 
+// uint8 fast path (W % 4 == 0): the halo window starts 3 pixels left of a 32-pixel boundary, so the aligned dwords from
+// one pixel further left cover it exactly: thread (row rr = tid/10, dword d = tid%10) of the first 210 loads ONE dword per
+// colour plane = 4 pixels x 3 channels, and writes them as four 8-byte (c0,c1,c2,0) pixels.  12 bytes per load-triple and
+// 4 LDS stores per thread per tile instead of 10 byte loads + 10 two-byte stores with per-element address arithmetic.
+struct StemRaw { uint32_t d[3]; };
+__device__ __forceinline__ StemRaw stem_issue4(const void* xv, int n, int H, int W, int hi0, int wi0) {
+  StemRaw r{{0u, 0u, 0u}};
+  const int tid = threadIdx.x;
+  if (tid < HR * 10) {
+    const int rr = tid / 10, d = tid - rr * 10;
+    const int h = hi0 + rr, w = wi0 - 1 + 4 * d;
+    if (h >= 0 && h < H && w >= 0 && w < W) {
+      const uint8_t* p = reinterpret_cast<const uint8_t*>(xv) + ((size_t)(n * 3) * H + h) * W + w;
+      const size_t plane = (size_t)H * W;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r.d[c] = *reinterpret_cast<const uint32_t*>(p + c * plane);
+    }
+  }
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void stem_commit4(T* halo, const StemRaw& r) {
+  const int tid = threadIdx.x;
+  if (tid >= HR * 10) return;
+  const int rr = tid / 10, d = tid - rr * 10;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int cc = 4 * d - 1 + j;
+    if (cc < 0 || cc >= HC) continue;
+    float f[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f[c] = (float)((r.d[c] >> (8 * j)) & 0xffu);
+    T* dst = halo + (rr * HC + cc) * 4;
+    if constexpr (sizeof(T) == 2) {
+      // 0..255 are exact in bf16: the upper half of the fp32 pattern
+      const uint32_t lo = (__float_as_uint(f[0]) >> 16) | (__float_as_uint(f[1]) & 0xffff0000u);
+      const uint32_t hi = __float_as_uint(f[2]) >> 16;
+      *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{lo, hi};
+    } else {
+      *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{f[0], f[1], f[2], 0.f};
+    }
+  }
+}
+
 template <typename T, bool INF32>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int tiles_h, int tiles_w, int ntiles) {
   constexpr bool BF = Elem<T>::DT == DT_BF16;
@@ -95,6 +139,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
     }
   }
   float pv[STEM_NEL];
+  StemRaw raw{{0u, 0u, 0u}};
+  const bool fast = !INF32 && (a.W & 3) == 0;
   // stage the packed weights [64][224] once
   {
     const char* wg = reinterpret_cast<const char*>(a.w);
@@ -110,8 +156,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
   if ((int)blockIdx.x < ntiles) {
     const int t0 = blockIdx.x;
     const int n = t0 / (tiles_h * tiles_w), rem = t0 - n * tiles_h * tiles_w;
-    stem_issue<INF32>(pv, role, a.x, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
-    stem_commit<T>(halo0, pv, role);
+    if (fast) {
+      raw = stem_issue4(a.x, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
+      stem_commit4<T>(halo0, raw);
+    } else {
+      stem_issue<INF32>(pv, role, a.x, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
+      stem_commit<T>(halo0, pv, role);
+    }
   }
   __syncthreads();
   float s1[16], s2[16];
@@ -129,7 +180,8 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
     const int nxt = tile + gridDim.x;
     if (nxt < ntiles) {
       const int nn = nxt / (tiles_h * tiles_w), nrem = nxt - nn * tiles_h * tiles_w;
-      stem_issue<INF32>(pv, role, a.x, nn, a.H, a.W, 2 * (nrem / tiles_w) * TH - 3, 2 * (nrem % tiles_w) * TW - 3);
+      if (fast) raw = stem_issue4(a.x, nn, a.H, a.W, 2 * (nrem / tiles_w) * TH - 3, 2 * (nrem % tiles_w) * TW - 3);
+      else stem_issue<INF32>(pv, role, a.x, nn, a.H, a.W, 2 * (nrem / tiles_w) * TH - 3, 2 * (nrem % tiles_w) * TW - 3);
     }
 
     f32x4_t acc[4][2];
@@ -178,6 +230,28 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
       }
     }
     // epilogue: lane holds kouts g*16 .. g*16+15 of pixel (ho0+2*wave+p, wo0+li)
+    // (the kernel is VALU-bound -- 56 MFMAs against ~650 VALU per tile and wave -- so the common training case, a full tile
+    // with no bias/ReLU, takes a path without the per-element selects, adds and the integer bf16 rounding)
+    if (ho0 + TH <= a.OH && wo0 + TW <= a.OW && !a.bias && !a.relu) {
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int ho = ho0 + 2 * wave + p, wo = wo0 + li;
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float q = acc[t][p][j];
+            s1[t * 4 + j] += q;
+            s2[t * 4 + j] = fmaf(q, q, s2[t * 4 + j]);
+            v[t * 4 + j] = q;
+          }
+        char* yp = reinterpret_cast<char*>(a.y) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64) * sizeof(T);
+        constexpr int EPC = Elem<T>::EPC;
+#pragma unroll
+        for (int q = 0; q < 16 / EPC; ++q) st16(yp + STEM_CH((q * EPC) >> 2, g, 0) * sizeof(T), PackH<T>::run(v + q * EPC));
+      }
+    } else
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int ho = ho0 + 2 * wave + p, wo = wo0 + li;
@@ -201,7 +275,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
           st16(yp + STEM_CH((q * EPC) >> 2, g, 0) * sizeof(T), Elem<T>::pack(v + q * EPC));
       }
     }
-    if (nxt < ntiles) stem_commit<T>(halo0 + (cur ^ 1) * (HR * HC * 4), pv, role);
+    if (nxt < ntiles) {
+      if (fast) stem_commit4<T>(halo0 + (cur ^ 1) * (HR * HC * 4), raw);
+      else stem_commit<T>(halo0 + (cur ^ 1) * (HR * HC * 4), pv, role);
+    }
     __syncthreads();
     cur ^= 1;
   }
@@ -244,43 +321,71 @@ template <typename T, bool INF32>
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, int tiles_h, int tiles_w, int ntiles) {
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int EPC = Elem<T>::EPC;
-  constexpr int PS = BF ? 32 : 16;               // pixels per step
+  constexpr int PS = BF ? 32 : 16;               // pixels per MFMA depth step
   constexpr int RB = 64 * sizeof(T);
   constexpr int CPR = RB / 16;
+  constexpr int YL = TH * TW * CPR / 256;        // dY staging loads per thread and tile (4 / 8)
+  constexpr int YBUF = TH * TW * RB, HBUF = HR * HC * 4 * sizeof(T);
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* ytile = smem;                            // [PS][RB] = 4 KiB
-  T* halo = reinterpret_cast<T*>(smem + PS * RB);
-
+  // two (dY tile, input halo) buffer pairs: the next tile's global loads are in flight during this tile's MFMAs and are
+  // written to the other pair afterwards -- one barrier per tile, no global latency between barriers
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
   const int row = tid / CPR, chunk = tid % CPR;
-  for (int i = tid; i < HR * HC * 4; i += 256) Elem<T>::st(halo + i, 0.f);
+  const bool fast = !INF32 && (a.W & 3) == 0;
+  for (int i = tid; i < 2 * (YBUF + HBUF) / 4; i += 256) reinterpret_cast<uint32_t*>(smem)[i] = 0u;
 
   f32x4_t acc[14];
 #pragma unroll
   for (int f = 0; f < 14; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  u32x4_t yreg[YL];
+  StemRaw raw{{0u, 0u, 0u}};
+  auto issue = [&](int tile) {
     const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
-    const int th = rem / tiles_w, tw = rem - th * tiles_w;
-    const int ho0 = th * TH, wo0 = tw * TW;
-    __syncthreads();
-    stem_load_halo<T, INF32>(halo, a.x, n, a.H, a.W, 2 * ho0 - 3, 2 * wo0 - 3);
+    const int ho0 = (rem / tiles_w) * TH, wo0 = (rem % tiles_w) * TW;
+    if (fast) raw = stem_issue4(a.x, n, a.H, a.W, 2 * ho0 - 3, 2 * wo0 - 3);
+#pragma unroll
+    for (int i = 0; i < YL; ++i) {
+      const int p = row + (256 / CPR) * i;
+      const int ho = ho0 + p / TW, wo = wo0 + p % TW;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (ho < a.OH && wo < a.OW)
+        v = ld16(reinterpret_cast<const char*>(a.dy) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64 + chunk * EPC) * sizeof(T));
+      yreg[i] = v;
+    }
+  };
+  auto commit = [&](int tile, int buf) {
+    char* yt = smem + buf * (YBUF + HBUF);
+    T* hl = reinterpret_cast<T*>(yt + YBUF);
+    if (fast) {
+      stem_commit4<T>(hl, raw);
+    } else {
+      const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
+      stem_load_halo<T, INF32>(hl, a.x, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
+    }
+#pragma unroll
+    for (int i = 0; i < YL; ++i) st16(yt + (row + (256 / CPR) * i) * RB + chunk * 16, yreg[i]);
+  };
+
+  __syncthreads();                               // zero fill (4th halo channel stays 0 on the slow path)
+  int cur = 0;
+  if ((int)blockIdx.x < ntiles) {
+    issue(blockIdx.x);
+    commit(blockIdx.x, 0);
+  }
+  __syncthreads();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < ntiles) issue(nxt);
+    const char* ytile = smem + cur * (YBUF + HBUF);
+    const T* halo = reinterpret_cast<const T*>(ytile + YBUF);
+#pragma unroll 1
     for (int step = 0; step < TH * TW / PS; ++step) {
-      // pixel p of the step -> (hl, wl) inside the tile
-      {
-        const int p = step * PS + row;
-        const int ho = ho0 + p / TW, wo = wo0 + p % TW;
-        u32x4_t v = {0u, 0u, 0u, 0u};
-        if (ho < a.OH && wo < a.OW)
-          v = ld16(reinterpret_cast<const char*>(a.dy) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64 + chunk * EPC) * sizeof(T));
-        __syncthreads();                         // previous step's reads of ytile are done
-        st16(ytile + row * RB + chunk * 16, v);
-      }
-      __syncthreads();
+      const char* ystep = ytile + step * PS * RB;
       if constexpr (BF) {
         // A: dY^T, kouts 16*wave + li, pixels 8g..8g+7
-        const char* pa = ytile + (8 * g + (li >> 2)) * RB + (16 * wave + (li & 3) * 4) * 2;
+        const char* pa = ystep + (8 * g + (li >> 2)) * RB + (16 * wave + (li & 3) * 4) * 2;
         s16x4_t alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(pa));
         s16x4_t ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(pa + 4 * RB));
         const bf16x8_t af = __builtin_bit_cast(bf16x8_t, (s16x8_t)__builtin_shufflevector(alo, ahi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -301,7 +406,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
 #pragma unroll
         for (int q = 0; q < PS / 4; ++q) {
           const int pl = 4 * q + g;
-          const float av = *reinterpret_cast<const float*>(ytile + pl * RB + (16 * wave + li) * 4);
+          const float av = *reinterpret_cast<const float*>(ystep + pl * RB + (16 * wave + li) * 4);
           const int p = step * PS + pl;
           const int hh = 2 * (p / TW), ww = 2 * (p % TW);
 #pragma unroll
@@ -313,6 +418,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
         }
       }
     }
+    if (nxt < ntiles) commit(nxt, cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
   // D[row = kout 16*wave+4g+j][col = feature li -> (s = s0 + li>>2, c = li&3)] -> dW[k][c][r][s]
 #pragma unroll
@@ -333,9 +441,16 @@ static hipError_t launch_stem_wgrad_t(const StemWgradArgs& a, hipStream_t st) {
   constexpr int PS = Elem<T>::DT == DT_BF16 ? 32 : 16;
   const int th = cdiv(a.OH, TH), tw = cdiv(a.OW, TW);
   const int ntiles = a.N * th * tw;
-  const size_t lds = PS * 64 * sizeof(T) + HR * HC * 4 * sizeof(T);
-  int grid = ntiles < 512 ? ntiles : 512;
-  hipLaunchKernelGGL((stem_wgrad_kernel<T, INF32>), dim3(grid), dim3(256), lds, st, a, th, tw, ntiles);
+  const size_t lds = 2 * (TH * TW * 64 * sizeof(T) + HR * HC * 4 * sizeof(T));
+  auto kern = stem_wgrad_kernel<T, INF32>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  int grid = ntiles < 768 ? ntiles : 768;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, th, tw, ntiles);
   return hipGetLastError();
 }
 
