@@ -1,0 +1,286 @@
+// Gather-form NHWC convolution fed entirely by global->LDS DMA: the stride-2 3x3 convs of ResNet18 (layer2.0/3.0/4.0 conv1),
+// their dgrads (four output-parity classes, each a tap subset -- see sslcr_conv_desc.pix_mul / tap_mask) and the 1x1
+// stride-2 downsample convs.  None of these has a producer BatchNorm in its load path (their input is a materialised block
+// output), so neither operand needs registers on the way to LDS:
+//
+//   * per step (one tap, one 128-byte channel slab) each lane issues global_load_lds_dwordx4 for its share of the BP pixel
+//     rows and BKO weight rows.  The lane picks its SOURCE 16-byte chunk so that the linear DMA placement is the XOR-
+//     swizzled (and, for weights, fragment-ordered) tile; a pixel that falls into the zero padding (or past M) reads a
+//     128-byte page of zeros instead -- no branches around memory operations, no ds_write, no staging VGPRs;
+//   * step j+1 is requested before the MFMAs of step j and waited for (vmcnt(0)) right before the barrier that ends
+//     step j; scheduler fences keep the requests where they are written (the compiler otherwise sinks them to the wait);
+//   * 256 threads, each wave a 64 px x 64 kout register tile (16 MFMA per 8 fragment reads), two workgroups per CU so one
+//     workgroup's barrier/epilogue phases sit under the other's MFMAs.
+//
+// Replaces conv_igemm_kernel for these shapes (274-370 TF/s forward at N=640 before).  Epilogue conventions (bias /
+// residual / ReLU / accumulate / strided scatter / per-channel (sum, sumsq) partial rows) are those of conv_igemm.hip.
+#include "kernels.hpp"
+
+namespace sslcr {
+
+__device__ __attribute__((aligned(128))) uint32_t g_conv_zero_page[32];   // zero-initialised: the padding source
+
+template <typename T> struct MmaD;
+template <> struct MmaD<bf16_t> {
+  __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+};
+template <> struct MmaD<float> {
+  __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
+  }
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T, int BP, int BKO>
+__global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int CE = 8 * EPC;                 // channels per 128-byte row = K depth of a step
+  constexpr int WP = BP / 64, WKN = 4 / WP;   // waves along pixels / kouts
+  static_assert(BKO == 64 * WKN, "each wave owns a 64 px x 64 kout tile");
+  constexpr int TK = 4, TP = 4;
+  constexpr int BB = BP * 128, AB = BKO * 128, STG = BB + AB;
+  constexpr int PLD = BP * 8 / 256, WLD = BKO * 8 / 256;     // DMA instructions per thread per step
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, li = lane & 15;
+  const int wp = wave % WP, wk = wave / WP;
+  const int m0 = blockIdx.x * BP, k0 = blockIdx.y * BKO;
+  const int PHW = a.PH * a.PW;
+  const int M = a.N * PHW;
+  const int pmul = a.pix_mul ? a.pix_mul : 1;
+  const int RS = a.R * a.S;
+  const int cslabs = a.C / CE;
+  const unsigned tmask = a.tap_mask ? a.tap_mask : ((1u << RS) - 1u);
+  const int nsteps = __builtin_popcount(tmask) * cslabs;
+
+  // ---- DMA roles: instruction i of this wave fills LDS rows [i*32 + wave*8, +8); lane -> (row, 16-byte slot)
+  const int slot = lane & 7;
+  int pbase[PLD], hb[PLD], wb[PLD], pc16[PLD];
+#pragma unroll
+  for (int i = 0; i < PLD; ++i) {
+    const int rr = i * 32 + wave * 8 + (lane >> 3);
+    const int m = m0 + rr;
+    pc16[i] = ((slot ^ (rr & 7)) * EPC) * (int)sizeof(T);
+    if (m < M) {
+      const int n = m / PHW, rem = m - n * PHW;
+      int ph = rem / a.PW, pw = rem - ph * a.PW;
+      ph = ph * pmul + a.pix_off_h; pw = pw * pmul + a.pix_off_w;
+      pbase[i] = n * a.H * a.W;
+      hb[i] = a.transposed ? ph + a.pad : ph * a.stride - a.pad;
+      wb[i] = a.transposed ? pw + a.pad : pw * a.stride - a.pad;
+    } else {
+      pbase[i] = -1; hb[i] = 0; wb[i] = 0;
+    }
+  }
+  int wsrc[WLD];
+#pragma unroll
+  for (int i = 0; i < WLD; ++i) {
+    const int rr = i * 32 + wave * 8 + (lane >> 3);
+    // inverse of wperm<TK>: LDS row t*16 + q*4 + j of a 64-row block holds kout row q*16 + t*4 + j
+    const int blk = rr >> 6, x = rr & 63;
+    const int krow = blk * 64 + ((x >> 2) & 3) * 16 + (x >> 4) * 4 + (x & 3);
+    wsrc[i] = (int)((((size_t)(k0 + krow) * RS) * a.C + (slot ^ (rr & 7)) * EPC) * sizeof(T));
+  }
+  const char* xg = reinterpret_cast<const char*>(a.x);
+  const char* wg = reinterpret_cast<const char*>(a.w);
+  const char* zpage = reinterpret_cast<const char*>(g_conv_zero_page) + slot * 16;
+
+  const int ssh = a.stride == 2 ? 1 : 0, smask = a.stride - 1;     // transposed form: stride 1 or 2 only (conv_dma_bp)
+  int it_tap = __builtin_ctz(tmask), it_slab = 0;      // issue() is called for steps 0,1,2,... in order
+  auto issue = [&](int stage) {
+    const int tap = it_tap, c0 = it_slab * CE;
+    if (++it_slab == cslabs) {
+      it_slab = 0;
+      do { ++it_tap; } while (it_tap < RS && !((tmask >> it_tap) & 1u));
+    }
+    const int r = tap / a.S, s = tap - r * a.S;
+    char* sb = smem + stage * STG;
+#pragma unroll
+    for (int i = 0; i < PLD; ++i) {
+      int h, w;
+      bool ok = pbase[i] >= 0;
+      if (a.transposed) {                        // dgrad gather: source pixel (p + pad - r) / stride where that divides
+        const int th = hb[i] - r, tw = wb[i] - s;
+        h = th >> ssh; w = tw >> ssh;
+        ok = ok && th >= 0 && tw >= 0 && ((th | tw) & smask) == 0;
+      } else {
+        h = hb[i] + r; w = wb[i] + s;
+        ok = ok && h >= 0 && w >= 0;
+      }
+      ok = ok && h < a.H && w < a.W;
+      const char* src = ok ? xg + ((size_t)(pbase[i] + h * a.W + w) * a.C + c0) * sizeof(T) + pc16[i] : zpage;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (i * 32 + wave * 8) * 128), 16, 0, 0);
+    }
+    const char* wtap = wg + ((size_t)tap * a.C + c0) * sizeof(T);
+#pragma unroll
+    for (int i = 0; i < WLD; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(wtap + wsrc[i]), (lptr_t)(sb + BB + (i * 32 + wave * 8) * 128), 16, 0, 0);
+  };
+
+  // fragment addresses: per-lane base (row & 7 == li & 7 for every fragment row) + immediates
+  int Ab[2], Bb[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int ci = kk * 4 + g;
+    Ab[kk] = BB + (wk * 64 + li) * 128 + ((ci ^ (li & 7)) << 4);
+    Bb[kk] = (wp * 64 + li) * 128 + ((ci ^ (li & 7)) << 4);
+  }
+
+  f32x4_t acc[TK][TP];
+#pragma unroll
+  for (int t = 0; t < TK; ++t)
+#pragma unroll
+    for (int p = 0; p < TP; ++p) acc[t][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  issue(0);
+  __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    if (step + 1 < nsteps) issue((step + 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const char* sb = smem + (step & 1) * STG;
+    u32x4_t A[2][TK], B[2][TP];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int t = 0; t < TK; ++t) A[kk][t] = ld16(sb + Ab[kk] + t * 2048);
+#pragma unroll
+      for (int p = 0; p < TP; ++p) B[kk][p] = ld16(sb + Bb[kk] + p * 2048);
+      if (kk == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int t = 0; t < TK; ++t)
+#pragma unroll
+        for (int p = 0; p < TP; ++p) MmaD<T>::run(A[kk][t], B[kk][p], acc[t][p]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+  }
+
+  // ---------------- epilogue: lane (li = pixel within 16-tile, g) holds kouts kb .. kb+15 of its pixels
+  const int kb = k0 + wk * 64 + g * (4 * TK);
+  float bias[4 * TK];
+  if (a.bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(a.bias + kb + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bias[4 * q + j] = b4[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4 * TK; ++j) bias[j] = 0.f;
+  }
+  char* yg = reinterpret_cast<char*>(a.y);
+  const char* rg = reinterpret_cast<const char*>(a.residual);
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    const int m = m0 + wp * 64 + p * 16 + li;
+    if (m >= M) continue;
+    const int n = m / PHW, rem = m - n * PHW;
+    int ph = rem / a.PW, pw = rem - ph * a.PW;
+    ph = ph * pmul + a.pix_off_h; pw = pw * pmul + a.pix_off_w;
+    const size_t opix = ((size_t)n * a.OH + (size_t)ph * a.osh) * a.OW + (size_t)pw * a.osh;
+    const size_t off = (opix * a.K + kb) * sizeof(T);
+    float v[4 * TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[t * 4 + j] = acc[t][p][j] + bias[t * 4 + j];
+#pragma unroll
+    for (int q = 0; q < 4 * TK / EPC; ++q) {
+      float* vq = v + q * EPC;
+      if (rg) {
+        float rr[EPC];
+        Elem<T>::unpack(ld16(rg + off + q * 16), rr);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
+      }
+      if (a.accumulate) {
+        float rr[EPC];
+        Elem<T>::unpack(ld16(yg + off + q * 16), rr);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) vq[e] = fmaxf(vq[e], 0.f);
+      }
+      st16(yg + off + q * 16, PackH<T>::run(vq));
+    }
+  }
+
+  if (a.stats) {
+    // rows >= M were staged as zeros -> contribute 0.  Sum over this wave's 64 pixels.
+    float s1[4 * TK], s2[4 * TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float x1 = 0.f, x2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < TP; ++p) { float q = acc[t][p][j]; x1 += q; x2 = fmaf(q, q, x2); }
+        s1[t * 4 + j] = row16_sum(x1);
+        s2[t * 4 + j] = row16_sum(x2);
+      }
+    if (li == 0) {
+      float* sp = a.stats + ((size_t)(blockIdx.x * WP + wp) * 2) * a.K + kb;
+#pragma unroll
+      for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
+    }
+  }
+}
+
+// 0: not applicable; else the pixel tile (128: 128 px x 128 kout, 256: 256 px x 64 kout)
+int conv_dma_bp(int dtype, const ConvArgs& a) {
+  if (a.in_scale != nullptr) return 0;
+  if (a.transposed && a.stride != 1 && a.stride != 2) return 0;
+  const int ce = dtype == DT_BF16 ? 64 : 32;
+  if (a.C % ce != 0 || a.K % 64 != 0 || a.R * a.S > 31) return 0;
+  const long M = (long)a.N * a.PH * a.PW;
+  if (M < 2048) return 0;                        // tiny problems stay on the 64x64-tile kernel
+  return a.K % 128 == 0 ? 128 : 256;
+}
+int conv_dma_rows(const ConvArgs& a, int bp) {
+  const int M = a.N * a.PH * a.PW;
+  return cdiv(M, bp) * (bp / 64);
+}
+
+template <typename T, int BP, int BKO>
+static hipError_t launch_d(const ConvArgs& a, hipStream_t st) {
+  const int M = a.N * a.PH * a.PW;
+  const size_t lds = 2 * (BP + BKO) * 128;
+  auto kern = conv_dma_kernel<T, BP, BKO>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(cdiv(M, BP), a.K / BKO), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_dma(int dtype, const ConvArgs& a, int bp, hipStream_t st) {
+  if (dtype == DT_BF16) return bp == 128 ? launch_d<bf16_t, 128, 128>(a, st) : launch_d<bf16_t, 256, 64>(a, st);
+  return bp == 128 ? launch_d<float, 128, 128>(a, st) : launch_d<float, 256, 64>(a, st);
+}
+
+const char* conv_dma_name(int dtype, int bp) {
+  if (dtype == DT_BF16) return bp == 128 ? "sslcr::conv_dma_kernel<unsigned short, 128, 128>" : "sslcr::conv_dma_kernel<unsigned short, 256, 64>";
+  return bp == 128 ? "sslcr::conv_dma_kernel<float, 128, 128>" : "sslcr::conv_dma_kernel<float, 256, 64>";
+}
+
+}  // namespace sslcr

@@ -276,6 +276,8 @@ int conv_partials_rows(const ConvArgs& a) {
   if (q) return conv_halo256_tiles(a, q) * 4;
   const int tw = conv_halo_tw(g_conv_dtype_hint, a);
   if (tw) return conv_halo_tiles(a, tw) * 2;
+  const int bp = conv_dma_bp(g_conv_dtype_hint, a);
+  if (bp) return conv_dma_rows(a, bp);
   const int M = a.N * a.PH * a.PW;
   return cdiv(M, conv_tile_bp(a)) * 2;
 }
@@ -316,6 +318,8 @@ const char* conv_kernel_name(int dtype, const ConvArgs& a) {
   }
   const int tw = q ? 0 : conv_halo_tw(dtype, a);
   if (tw && conv_halo_tw(DT_BF16, a) == tw) return bf ? "sslcr::conv3x3_halo_kernel<unsigned short, ...>" : "sslcr::conv3x3_halo_kernel<float, ...>";
+  const int dbp = (q || tw) ? 0 : conv_dma_bp(dtype, a);
+  if (dbp && conv_dma_bp(DT_BF16, a) == dbp) return conv_dma_name(dtype, dbp);
   const int bp = conv_tile_bp(a);
   if (bp == 128) {
     if (wide) return bf ? "sslcr::conv_igemm_kernel<unsigned short, 128, 128>" : "sslcr::conv_igemm_kernel<float, 128, 128>";
@@ -330,6 +334,8 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
   if (q && conv_halo256_mode(DT_BF16, a) == q) return launch_conv_halo256(dtype, a, q, st);
   const int tw = q ? 0 : conv_halo_tw(dtype, a);
   if (tw && conv_halo_tw(DT_BF16, a) == tw) return launch_conv_halo(dtype, a, tw, st);   // (same tiling in both dtypes)
+  const int dbp = (q || tw) ? 0 : conv_dma_bp(dtype, a);
+  if (dbp && conv_dma_bp(DT_BF16, a) == dbp) return launch_conv_dma(dtype, a, dbp, st);
   return dtype == DT_BF16 ? launch_t<bf16_t>(a, st) : launch_t<float>(a, st);
 }
 

@@ -38,6 +38,11 @@ hipError_t launch_conv_halo256(int dtype, const ConvArgs& a, int mode, hipStream
 bool conv_h16_ok(int dtype, const ConvArgs& a);
 hipError_t launch_conv_h16(int dtype, const ConvArgs& a, hipStream_t st);
 const char* conv_h16_name(int dtype, const ConvArgs& a);
+// conv_dma.hip
+int conv_dma_bp(int dtype, const ConvArgs& a);
+int conv_dma_rows(const ConvArgs& a, int bp);
+hipError_t launch_conv_dma(int dtype, const ConvArgs& a, int bp, hipStream_t st);
+const char* conv_dma_name(int dtype, int bp);
 // conv_wgrad.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 int wgrad_halo_tw(const WgradArgs& a);
