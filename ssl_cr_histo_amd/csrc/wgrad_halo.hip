@@ -31,12 +31,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
   constexpr int TH = 8;
   constexpr int NI = 128 / (TH * TW);
   constexpr int HH = TH + 2, HWD = TW + 2;
-  constexpr int HP = NI * HH * HWD;             // 180 / 200 halo pixels
+  constexpr int HP = NI * HH * HWD;             // 180 / 200 halo pixels staged per tile
   constexpr int YL = 128 * CPR / 256;           // dY staging loads per thread (4 / 8)
   constexpr int HL = (HP * CPR + 255) / 256;    // halo staging loads per thread
-  constexpr int YBUF = 128 * RB, HBUF = HP * RB;
+  // bf16: halo rows are pitched to 24 (16-wide tiles) / 16 pixels -- multiples of 8 -- so that bits 1..2 of a halo pixel
+  // index depend on the lane and the filter COLUMN only: the bank swizzle below is then a per-lane constant per column and
+  // every transpose read is base register + immediate (3 + 4 address registers for all nine taps)
+  constexpr int PITCH = BF ? (TW == 16 ? 24 : 16) : HWD;
+  constexpr int YBUF = 128 * RB, HBUF = NI * HH * PITCH * RB;
   constexpr int BUF = YBUF + HBUF;
-  constexpr int NBUF = (BF && TW == 16) ? 2 : 1;   // 8-wide tiles (84 KiB double-buffered) and fp32: single buffer so two workgroups fit a CU
+  constexpr int NBUF = 1;                       // single (dY, halo) buffer: two workgroups share a CU and cover each other's staging
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -44,11 +48,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
   const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const int chunk = tid % CPR, prow = tid / CPR;          // staging role
   const bool xform = a.in_scale != nullptr;
-  float r_scale[EPC], r_shift[EPC];
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    r_scale[e] = xform ? a.in_scale[c0 + chunk * EPC + e] : 1.f;
-    r_shift[e] = xform ? a.in_shift[c0 + chunk * EPC + e] : 0.f;
+  // producer BN scale/shift of this workgroup's 64 input channels: kept in LDS (behind the tile buffer) and read when a
+  // halo is staged -- as registers they cost 16 VGPRs through the MFMA loop, which is register-bound
+  float* s_aff = reinterpret_cast<float*>(smem + NBUF * BUF);
+  if (tid < 64) {
+    s_aff[tid] = xform ? a.in_scale[c0 + tid] : 1.f;
+    s_aff[64 + tid] = xform ? a.in_shift[c0 + tid] : 0.f;
   }
   const int tiles_w = a.W / TW, tiles_h = a.H / TH;
   const int t_begin = blockIdx.z * tiles_per_split;
@@ -112,15 +117,34 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
       hreg[i] = v;
     }
   };
+  // Bank swizzle of the bf16 tiles.  A transpose read presents, per 32 lanes, 8 pixel rows x 32 bytes at ONE column offset;
+  // rows are 128 B = half the banks apart, so unswizzled the four same-parity rows collide 4-way (measured: 68 % of the
+  // kernel's LDS cycles were bank conflicts).  The lanes are mapped so that those 8 rows are 8 CONSECUTIVE pixels of one
+  // image row, and the 32-byte column group is XORed with bits 1..2 of the row index.
+  auto swz = [](int row) { return (row >> 1) & 3; };
+  auto chunk_off = [&](int row) {               // byte offset of staging chunk `chunk` inside its row
+    if (!BF) return chunk * 16;
+    return (((chunk >> 1) ^ swz(row)) << 5) | ((chunk & 1) << 4);
+  };
   auto store_lds = [&](int buf) {
     char* yb = smem + buf * BUF;
     char* hb = yb + YBUF;
+    float r_scale[EPC], r_shift[EPC];
+    if (xform) {
 #pragma unroll
-    for (int i = 0; i < YL; ++i) st16(yb + (prow + (256 / CPR) * i) * RB + chunk * 16, yreg[i]);
+      for (int e = 0; e < EPC; ++e) { r_scale[e] = s_aff[chunk * EPC + e]; r_shift[e] = s_aff[64 + chunk * EPC + e]; }
+    }
+#pragma unroll
+    for (int i = 0; i < YL; ++i) {
+      const int p = prow + (256 / CPR) * i;
+      st16(yb + p * RB + chunk_off(p), yreg[i]);
+    }
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
       const int hp = prow + (256 / CPR) * i;
       if (hp >= HP) continue;
+      const int hni = hp / (HH * HWD), hrem = hp - hni * (HH * HWD);
+      const int hpl = (hni * HH + hrem / HWD) * PITCH + hrem % HWD;      // pitched LDS pixel index
       u32x4_t v = hreg[i];
       if (xform && ((hin >> i) & 1u)) {
         float f[EPC];
@@ -132,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
         }
         v = Elem<T>::pack(f);
       }
-      st16(hb + hp * RB + chunk * 16, v);
+      st16(hb + hpl * RB + chunk_off(hpl), v);
     }
   };
 
@@ -144,11 +168,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
 
   // halo pixel index of tile pixel p, tap (0,0)
   auto hpix = [&](int p) {
-    if (TW == 16) return (p >> 4) * HWD + (p & 15);
-    return (p >> 6) * (HH * HWD) + ((p >> 3) & 7) * HWD + (p & 7);
+    if (TW == 16) return (p >> 4) * PITCH + (p & 15);
+    return (p >> 6) * (HH * PITCH) + ((p >> 3) & 7) * PITCH + (p & 7);
   };
 
   load_regs(t_begin);
+  __syncthreads();                              // s_aff
   store_lds(0);
   __syncthreads();
   int buf = 0;
@@ -157,44 +182,33 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
     if (more) load_regs(tile + 1);
     const char* yb = smem + buf * BUF;
     const char* hb = yb + YBUF;
-    if constexpr (BF && TW == 8) {
-#pragma unroll 1
-      for (int q = 0; q < 4; ++q) {              // 32-pixel MFMA depth steps of the 128-pixel tile (unrolling it spills)
-        const int p0 = q * 32 + 8 * g + (li >> 2);          // this lane's source pixels for the transpose reads
-        bf16x8_t af[4];
-#pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-          const char* pa = yb + p0 * RB + (16 * t4 + (li & 3) * 4) * 2;
-          af[t4] = tr_pair(pa, pa + 4 * RB);
-        }
-        const int h0p = hpix(p0), h1p = hpix(p0 + 4);
-        const int coff = (16 * wave + (li & 3) * 4) * 2;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int toff = (t / 3) * HWD + (t % 3);
-          const bf16x8_t bfrag = tr_pair(hb + (h0p + toff) * RB + coff, hb + (h1p + toff) * RB + coff);
-#pragma unroll
-          for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t4], bfrag, acc[t][t4], 0, 0, 0);
-        }
-      }
-    } else if constexpr (BF) {
+    if constexpr (BF) {
       // 32-pixel MFMA depth steps of the 128-pixel tile.  The B fragment of the NEXT tap (or of tap 0 of the next depth
       // step) is requested before the four MFMAs of this tap; scheduler fences keep it that way (left alone the compiler
       // emits read -> wait -> 4 MFMA per tap and the matrix pipe idles for an LDS round trip nine times per step).
-      const int coff = (16 * wave + (li & 3) * 4) * 2;
+      // this lane's source pixels within a 32-pixel depth step: pl and pl + 8 (any lane -> pixel map works as long as dY and
+      // X use the same one; this one keeps the 8 pixel rows of a 32-lane group consecutive, see swz)
+      const int pl = 16 * (g >> 1) + 4 * (g & 1) + (li >> 2);
+      constexpr int HI = (TW == 16 ? 8 : PITCH) * RB;       // halo byte offset of pixel pl + 8 (8-wide tiles: next image row)
+      int Aoff[4], Boff[3];
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) Aoff[t4] = pl * RB + ((t4 ^ swz(pl)) << 5) + (li & 3) * 8;
+#pragma unroll
+      for (int sx = 0; sx < 3; ++sx) {
+        const int hp = hpix(pl) + sx;
+        Boff[sx] = hp * RB + ((wave ^ swz(hp)) << 5) + (li & 3) * 8;
+      }
       bf16x8_t bfr[2];
       auto bfrag_of = [&](int q, int t) {
-        const int p0 = q * 32 + 8 * g + (li >> 2);
-        const int toff = (t / 3) * HWD + (t % 3);
-        return tr_pair(hb + (hpix(p0) + toff) * RB + coff, hb + (hpix(p0 + 4) + toff) * RB + coff);
+        const int qoff = (hpix(q * 32) + (t / 3) * PITCH) * RB;       // depth step and filter row: uniform byte offset
+        return tr_pair(hb + Boff[t % 3] + qoff, hb + Boff[t % 3] + qoff + HI);
       };
       auto qstep = [&](const int q, const int par) {       // par: which of bfr[] holds (q, tap 0)
-        const int p0 = q * 32 + 8 * g + (li >> 2);          // this lane's source pixels for the transpose reads
         bf16x8_t af[4];
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
-          const char* pa = yb + p0 * RB + (16 * t4 + (li & 3) * 4) * 2;
-          af[t4] = tr_pair(pa, pa + 4 * RB);
+          const char* pa = yb + q * 32 * RB + Aoff[t4];
+          af[t4] = tr_pair(pa, pa + 8 * RB);
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -222,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
         const int hp0 = hpix(p);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const int toff = (t / 3) * HWD + (t % 3);
+          const int toff = (t / 3) * PITCH + (t % 3);
           const float bv = *reinterpret_cast<const float*>(hb + (hp0 + toff) * RB + (16 * wave + li) * 4);
 #pragma unroll
           for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv, acc[t][t4], 0, 0, 0);
@@ -267,7 +281,9 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   if (splits < 1) splits = 1;
   const int tps = cdiv(ntiles, splits);
   splits = cdiv(ntiles, tps);
-  const size_t lds = (size_t)((BF && TW == 16) ? 2 : 1) * (128 + HP) * 64 * sizeof(T);
+  const int pitch = BF ? (TW == 16 ? 24 : 16) : TW + 2;
+  const size_t lds = (size_t)(128 + NI * 10 * pitch) * 64 * sizeof(T) + 512;
+  (void)HP;
   auto kern = wgrad3x3_halo_kernel<T, TW>;
   static bool attr_done = false;
   if (!attr_done) {
