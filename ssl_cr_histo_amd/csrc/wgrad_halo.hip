@@ -275,7 +275,14 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   constexpr int HP = NI * 10 * (TW + 2);
   const int ntiles = (a.N / NI) * (a.H / 8) * (a.W / TW);
   const int kc = (a.K / 64) * (a.C / 64);
-  int splits = cdiv(1024, kc);
+  // exactly one resident round: two workgroups per CU.  The pixel split decides how many fp32 atomics hit dW
+  // (workgroups x 64x64x9): with twice as many workgroups the final atomics alone were 22 % of the kernel.
+  int cus = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  int splits = cdiv(2 * cus, kc);
   const int max_splits = cdiv(ntiles, 2);                 // at least 2 tiles (256 pixels) per workgroup
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
