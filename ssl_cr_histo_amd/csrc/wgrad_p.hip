@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256, 1) void wgrad3x3_p_kernel(const WgradArgs a, i
 // 0: not applicable; else the cin block (128 / 64)
 int wgrad_p_cb(int dtype, const WgradArgs& a, int tw) {
   if (dtype != DT_BF16 || !tw) return 0;
-  if (!getenv("SSLCR_WGRAD_P")) return 0;       // experimental: slower than wgrad_halo so far
+  static const bool on = getenv("SSLCR_WGRAD_P") != nullptr;       // experimental: slower than wgrad_halo so far
+  if (!on) return 0;
   (void)a;
   return 64;          // the 128-channel block (288 accumulators + 16 staging items) does not fit 256 + 256 registers yet
 }
