@@ -169,7 +169,13 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
   const int M = a.N * a.OH * a.OW;
   const int total_steps = cdiv(M, PS);
   const int tiles = (a.K / 64) * (a.C / 64);
-  int splits = cdiv(1024, tiles);
+  // one resident round (two workgroups per CU): the pixel split sets how many fp32 atomics hit dW, see wgrad_halo.hip
+  int cus = 256;
+  {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  int splits = cdiv(TAPS == 1 ? 4 * cus : 2 * cus, tiles);     // 1x1: few atomics per workgroup, more parallel slices pay
   const int max_splits = cdiv(total_steps, 8);      // at least 8 steps per workgroup
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
