@@ -73,6 +73,11 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   char* s_w = smem + HBUF;                    // [2][TPB][BKO][128 B]
   float* s_scale = reinterpret_cast<float*>(smem + HBUF + 2 * TPB * WBUF);
   float* s_shift = s_scale + a.C;
+  // BatchNorm (sum, sumsq) of this workgroup's current kout block, per 64-pixel wave row: [4][2][BKO].  Items add into
+  // it with ds_add_f32 (each entry has exactly one writer wave, so the order -- and the fp32 result -- is deterministic);
+  // it is written out as ONE set of four partial rows per workgroup and kout block instead of four rows per tile
+  // (40960 partial rows -> 1024 for the layer1 shape: the second-stage row reduction was 2.4 % of the step).
+  float* s_stat = s_shift + a.C;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,6 +86,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   const int tiles_w = a.W / TW, tiles_h = a.H / TH;
   if (XF)
     for (int c = tid; c < a.C; c += NT) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
+  for (int i = tid; i < 8 * BKO; i += NT) s_stat[i] = 0.f;
   const float relu_lo = a.in_relu ? 0.f : -__builtin_inff();
 
   // XCD-aware walk: blocks land on XCD (blockIdx % 8); each XCD takes a contiguous run of tiles per round so that
@@ -335,9 +341,21 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
             s2[t * 4 + j] = row16_sum(x2);
           }
         if (li == 0) {
-          float* sp = a.stats + ((size_t)(cur.tile * 4 + wp) * 2) * a.K + kb;
+          float* sp = s_stat + (wp * 2) * BKO + wk * (BKO / WK) + g * (4 * TK);
 #pragma unroll
-          for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
+          for (int j = 0; j < 4 * TK; ++j) {
+            __hip_atomic_fetch_add(sp + j, s1[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(sp + BKO + j, s2[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+        if (done || nxt.k0 != cur.k0) {           // last item of this kout block: publish the four rows (uniform branch)
+          __syncthreads();
+          for (int i = tid; i < 8 * BKO; i += NT) {
+            const int rw = i / BKO, c = i - rw * BKO;        // rw = wave row * 2 + (0: sum, 1: sumsq)
+            a.stats[((size_t)(blockIdx.x * 4 + (rw >> 1)) * 2 + (rw & 1)) * a.K + cur.k0 + c] = s_stat[i];
+            s_stat[i] = 0.f;
+          }
+          __syncthreads();
         }
       }
       if (done) break;
@@ -349,6 +367,16 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
       cur = nxt;
     }
     slab = nslab;
+  }
+  if (a.stats) {
+    const int kb_first = first / tiles_total, kb_last = item / tiles_total;      // item = the last one processed
+    for (int kbi = 0; kbi < a.K / BKO; ++kbi) {
+      if (kbi >= kb_first && kbi <= kb_last) continue;
+      for (int i = tid; i < 8 * BKO; i += NT) {
+        const int rw = i / BKO, c = i - rw * BKO;
+        a.stats[((size_t)(blockIdx.x * 4 + (rw >> 1)) * 2 + (rw & 1)) * a.K + kbi * BKO + c] = 0.f;
+      }
+    }
   }
 }
 
@@ -365,10 +393,16 @@ static int device_cus() {
 bool conv_h16_ok(int dtype, const ConvArgs& a) {
   return conv_halo256_mode(dtype, a) == 16 && conv_halo256_mode(DT_BF16, a) == 16;
 }
+// partial-statistics rows the launch will write: four per workgroup (see s_stat)
+int conv_h16_rows(const ConvArgs& a) {
+  const int bko = a.K % 128 == 0 ? 128 : 64;
+  const int n_items = a.N * (a.H / 16) * (a.W / 16) * (a.K / bko);
+  return (n_items < device_cus() ? n_items : device_cus()) * 4;
+}
 
 template <typename T, int BKO, int WK, bool XF>
 static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
-  const size_t lds = 18 * 24 * 128 + 2 * 3 * BKO * 128 + 2 * a.C * sizeof(float);
+  const size_t lds = 18 * 24 * 128 + 2 * 3 * BKO * 128 + 2 * a.C * sizeof(float) + 8 * BKO * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   auto kern = conv3x3_h16_kernel<T, BKO, WK, XF>;
   static bool attr_done = false;

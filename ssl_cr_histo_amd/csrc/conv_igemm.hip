@@ -272,6 +272,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st) {
 
 static int g_conv_dtype_hint = DT_BF16;   // conv_partials_rows() is asked before the launch: both dtypes tile identically
 int conv_partials_rows(const ConvArgs& a) {
+  if (conv_h16_ok(g_conv_dtype_hint, a)) return conv_h16_rows(a);
   const int q = conv_halo256_mode(g_conv_dtype_hint, a);
   if (q) return conv_halo256_tiles(a, q) * 4;
   const int tw = conv_halo_tw(g_conv_dtype_hint, a);

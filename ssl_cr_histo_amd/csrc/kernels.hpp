@@ -36,6 +36,7 @@ int conv_halo256_tiles(const ConvArgs& a, int mode);
 hipError_t launch_conv_halo256(int dtype, const ConvArgs& a, int mode, hipStream_t st);
 // conv_h16.hip
 bool conv_h16_ok(int dtype, const ConvArgs& a);
+int conv_h16_rows(const ConvArgs& a);
 hipError_t launch_conv_h16(int dtype, const ConvArgs& a, hipStream_t st);
 const char* conv_h16_name(int dtype, const ConvArgs& a);
 // conv_dma.hip
