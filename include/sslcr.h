@@ -48,6 +48,9 @@ typedef struct sslcr_conv_desc {
 } sslcr_conv_desc;
 int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream);
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d);
+/* name of the kernel instance sslcr_conv2d would launch for this descriptor, spelled as rocprofv3 prints it (static string;
+   lets tests and profiles tie a shape to the code path that serves it) */
+const char* sslcr_conv2d_kernel_name(int dtype, const sslcr_conv_desc* d);
 
 /* ---- conv2d weight gradient (autograd wgrad of the same convs) */
 typedef struct sslcr_wgrad_desc {

@@ -65,6 +65,7 @@ SIGNATURES = {
     "sslcr_last_error": (C.c_char_p, []),
     "sslcr_conv2d": (i32, [i32, P(ConvDesc), vp]),
     "sslcr_conv2d_partial_rows": (i32, [P(ConvDesc)]),
+    "sslcr_conv2d_kernel_name": (C.c_char_p, [i32, P(ConvDesc)]),
     "sslcr_conv2d_wgrad": (i32, [i32, P(WgradDesc), vp]),
     "sslcr_probe_tr16": (i32, [vp, vp, vp, vp]),
     "sslcr_stem_conv": (i32, [i32, P(StemDesc), vp]),

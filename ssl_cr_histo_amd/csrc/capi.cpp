@@ -43,6 +43,7 @@ int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream) {
   return check(launch_conv(dtype, *d, (hipStream_t)stream), "conv2d");
 }
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d) { return d ? conv_partials_rows(*d) : -1; }
+const char* sslcr_conv2d_kernel_name(int dtype, const sslcr_conv_desc* d) { return d ? conv_kernel_name(dtype, *d) : ""; }
 
 int sslcr_conv2d_wgrad(int dtype, const sslcr_wgrad_desc* d, void* stream) {
   DT_OK(dtype);

@@ -31,6 +31,9 @@ def _chk(*ts):
                 raise L.SslcrError("sslcr kernels need contiguous tensors")
 
 
+last_conv_kernel = ""       # kernel instance the most recent conv2d() launched (rocprofv3 spelling), for tests / profiles
+
+
 def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bias=None, residual=None, relu=False,
            want_stats=False, out=None, transposed=False, out_hw=None, osh=1, accumulate=False, pixel_hw=None,
            pix_mul=0, pix_off=(0, 0), tap_mask=0):
@@ -56,6 +59,8 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
         rows = L.lib().sslcr_conv2d_partial_rows(d)
         stats = torch.empty((rows, 2, K), dtype=torch.float32, device=x.device)
         d.stats = L.ptr(stats)
+    global last_conv_kernel
+    last_conv_kernel = L.lib().sslcr_conv2d_kernel_name(dt, d).decode()
     L.check(L.lib().sslcr_conv2d(dt, d, L.stream_ptr()))
     return (y, stats) if want_stats else y
 

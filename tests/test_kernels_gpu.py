@@ -75,6 +75,10 @@ CONV_CASES = [
     (3, 24, 48, 64, 128, 3, 1, 1),     # halo kernel, several tiles per image
     (4, 8, 8, 512, 512, 3, 1, 1),      # 256-pixel halo kernel, 4 images x 8x8, 8 slabs
     (2, 32, 32, 128, 256, 3, 1, 1),    # 256-pixel halo kernel, 16x16 tiles, 2 slabs
+    (33, 32, 32, 64, 256, 3, 1, 1),    # persistent h16: 264 items > 256 workgroups, a workgroup walks into the next kout block
+    (10, 30, 34, 64, 128, 3, 2, 1),    # all-DMA gather conv: stride 2, ragged M = 2550, 128x128 tiles
+    (10, 30, 34, 128, 64, 3, 2, 1),    # all-DMA gather conv: 256x64 tiles, 2 channel slabs
+    (9, 32, 32, 64, 128, 1, 2, 0),     # all-DMA gather conv: 1x1/2 projection
 ]
 
 
@@ -86,6 +90,12 @@ def test_conv_fwd_raw_stats(case, dtype):
     x = q(rnd(1, (N, H, W, C)), dtype)
     w = q(rnd(2, (Ko, Rr, Rr, C), 0.05), dtype)
     y, stats = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), stride, pad, want_stats=True)
+    # the shapes added for a specific kernel must actually be served by it
+    expect = {(33, 32, 32, 64, 256, 3, 1, 1): "conv3x3_h16_kernel", (10, 30, 34, 64, 128, 3, 2, 1): "conv_dma_kernel",
+              (10, 30, 34, 128, 64, 3, 2, 1): "conv_dma_kernel", (9, 32, 32, 64, 128, 1, 2, 0): "conv_dma_kernel",
+              (4, 8, 8, 512, 512, 3, 1, 1): "conv3x3_halo256_kernel"}.get(case)
+    if expect:
+        assert expect in K.last_conv_kernel, K.last_conv_kernel
     want = R.conv_fwd(x, w, stride, pad)
     close(y, want, TOL[dtype], "conv raw")
     s, ss = R.channel_stats(want)
@@ -115,7 +125,9 @@ def test_conv_fwd_fused_prologue_epilogue(shape, dtype):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 9, 11, 64, 128, 3, 2, 1), (2, 8, 8, 128, 256, 1, 2, 0),
-                                  (2, 10, 10, 256, 256, 3, 1, 1)])
+                                  (2, 10, 10, 256, 256, 3, 1, 1),
+                                  (10, 30, 34, 64, 128, 3, 2, 1),     # all-DMA gather conv: transposed + parity-class forms
+                                  (10, 32, 32, 128, 256, 1, 2, 0)])   # all-DMA gather conv: 1x1 scatter-accumulate
 def test_conv_dgrad(case, dtype):
     K = _k()
     N, H, W, C, Ko, Rr, stride, pad = case
@@ -148,6 +160,8 @@ def test_conv_dgrad(case, dtype):
                 K.conv2d(to_dev(dy, dtype), to_dev(wd, dtype), stride, pad, transposed=True, out=dx3, out_hw=(H, W),
                          pixel_hw=((H - ph_ + 1) // 2, (W - pw_ + 1) // 2), residual=to_dev(res, dtype), pix_mul=2,
                          pix_off=(ph_, pw_), tap_mask=m)
+                if N * H * W >= 4 * 2048:
+                    assert "conv_dma_kernel" in K.last_conv_kernel, K.last_conv_kernel
             close(dx3, want + res, TOL[dtype], "dgrad by parity classes")
         if stride == 1:
             # the engine's form: tap-flipped [C][R][S][K] pack => the dgrad is a plain 3x3 conv of dY (halo kernel when it tiles)
