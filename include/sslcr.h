@@ -129,6 +129,9 @@ typedef struct sslcr_bn_bwd_desc {
   const void* pool_dy;    /* optional: dy is not given directly but through maxpool3x3/2 pad 1 -- pooled gradient [N][pOH][pOW][C] ... */
   const uint8_t* pool_argmax;   /* ... and the argmax codes recorded by sslcr_bn_relu_maxpool; x is then [N][pH][pW][C] */
   int pH, pW, pOH, pOW;
+  const void* pool_y;     /* optional with pool_dy: the max-pool OUTPUT saved by the forward, [N][pOH][pOW][C].  With it the reduce
+                             pass reads only the pooled tensors: a pooled gradient lands on exactly one input pixel, whose
+                             relu(bn(x)) IS the pooled output, so (x - mean) = (y - shift) / scale - mean where y > 0 */
 } sslcr_bn_bwd_desc;
 int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream);

@@ -433,6 +433,158 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
   }
 }
 
+// ---- stem form: the gradient arrives through maxpool3x3/2 (pool_dy + argmax codes), see sslcr_bn_bwd_desc.
+// Reduce pass on the POOLED tensors only (4x fewer elements, no 1.3 GB read of x): every pooled gradient lands on exactly one
+// input pixel -- the argmax -- and relu(bn(x)) of that pixel IS the pooled output y, so for y > 0
+//     g = dy_pool,   (x - mean) = (y - shift) / scale - mean
+// and for y == 0 the ReLU mask kills the gradient.  A channel with scale == 0 (gamma exactly 0) cannot be inverted: those
+// lanes fetch x at the argmax position instead.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  __shared__ float sm[256][2 * EPC + 1];
+  const int cols = a.C / EPC;
+  const int rpp = 256 / cols;
+  const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+  const int cb = col * EPC;
+  float s0[EPC], s1[EPC], mean[EPC], rinv[EPC], rsh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    s0[e] = 0.f; s1[e] = 0.f; mean[e] = a.mean[cb + e]; rsh[e] = a.shift[cb + e];
+    const float sc = a.scale[cb + e];
+    rinv[e] = sc != 0.f ? 1.f / sc : 0.f;
+  }
+  const size_t ppix = (a.pixels / ((size_t)a.pH * a.pW)) * a.pOH * a.pOW;      // pooled pixels
+  if (rl < rpp) {
+    for (size_t p = (size_t)blockIdx.x * rpp + rl; p < ppix; p += (size_t)gridDim.x * rpp) {
+      float d[EPC], y[EPC];
+      Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.pool_dy) + (p * cols + col) * 16), d);
+      Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.pool_y) + (p * cols + col) * 16), y);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        if (a.relu_from_x && !(y[e] > 0.f)) continue;
+        float xm;
+        if (rinv[e] != 0.f) {
+          xm = (y[e] - rsh[e]) * rinv[e] - mean[e];
+        } else {
+          const int code = a.pool_argmax[p * a.C + cb + e];
+          size_t q = p;
+          const int ow = (int)(q % a.pOW); q /= a.pOW;
+          const int oh = (int)(q % a.pOH); const size_t n = q / a.pOH;
+          const int h = 2 * oh - 1 + code / 3, w = 2 * ow - 1 + code % 3;
+          xm = Elem<T>::ld(reinterpret_cast<const T*>(a.x) + ((n * a.pH + h) * a.pW + w) * a.C + cb + e) - mean[e];
+        }
+        s0[e] += d[e];
+        s1[e] = fmaf(d[e], xm, s1[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { sm[threadIdx.x][e] = s0[e]; sm[threadIdx.x][EPC + e] = s1[e]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < cols * 2 * EPC; t += 256) {
+    const int cc = t / (2 * EPC), q = t - cc * 2 * EPC;
+    double acc = 0.0;
+    for (int r = 0; r < rpp; ++r) acc += (double)sm[r * cols + cc][q];
+    const int which = q / EPC, e = q - which * EPC;
+    atomicAdd(&a.sums[(size_t)which * a.C + cc * EPC + e], acc);
+  }
+}
+
+// Apply pass of the stem form on 2x2 input-pixel blocks: the four pixels (2a+i, 2b+j) share the four pooling windows
+// (a+di, b+dj), so a thread loads 4 windows (gradient chunk + argmax codes) for 4 pixels instead of 4 per pixel, and the
+// argmax code a window must carry to select pixel (i,j) is a compile-time constant (i - 2di + 1) * 3 + (j - 2dj + 1).
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const BnBwdArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = a.C / EPC;
+  const int BH = (a.pH + 1) / 2, BW = (a.pW + 1) / 2;
+  const size_t N = a.pixels / ((size_t)a.pH * a.pW);
+  const size_t total = N * BH * BW * cols;
+  const float invM = (float)(1.0 / a.count);
+  const int cb = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % cols) * EPC;      // grid stride is a multiple of cols
+  float cA[EPC], cB[EPC], cC[EPC], rsh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    const int c = cb + e;
+    const float is = a.invstd[c], sc = a.scale[c];
+    const float m0 = (float)a.sums[c] * invM, m1 = (float)a.sums[a.C + c] * invM;
+    cA[e] = sc;
+    cB[e] = -sc * is * is * m1;
+    cC[e] = -sc * m0 - cB[e] * a.mean[c];
+    rsh[e] = a.shift[c];
+  }
+  const char* xg = reinterpret_cast<const char*>(a.x);
+  const char* dyg = reinterpret_cast<const char*>(a.pool_dy);
+  char* dxg = reinterpret_cast<char*>(a.dx);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int col = (int)(i % cols);
+    size_t q = i / cols;
+    const int bw = (int)(q % BW); q /= BW;
+    const int bh = (int)(q % BH); const size_t n = q / BH;
+    // the four windows: unconditional loads from clamped addresses, validity applied by select
+    u32x4_t dv[2][2];
+    uint32_t am[2][2][2];
+    bool wok[2][2];
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) {
+        const int oh = bh + di, ow = bw + dj;
+        wok[di][dj] = oh < a.pOH && ow < a.pOW;
+        const int ohc = oh < a.pOH ? oh : a.pOH - 1, owc = ow < a.pOW ? ow : a.pOW - 1;
+        const size_t o = ((n * a.pOH + ohc) * a.pOW + owc) * cols + col;
+        dv[di][dj] = ld16_nt(dyg + o * 16);
+        if (EPC == 8) { const u32x2_t v = *reinterpret_cast<const u32x2_t*>(a.pool_argmax + o * EPC); am[di][dj][0] = v[0]; am[di][dj][1] = v[1]; }
+        else { am[di][dj][0] = *reinterpret_cast<const uint32_t*>(a.pool_argmax + o * EPC); am[di][dj][1] = 0; }
+      }
+    u32x4_t xv[2][2];
+    bool pok[2][2];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj) {
+        const int h = 2 * bh + pi, w = 2 * bw + pj;
+        pok[pi][pj] = h < a.pH && w < a.pW;
+        const int hc = h < a.pH ? h : a.pH - 1, wc = w < a.pW ? w : a.pW - 1;
+        xv[pi][pj] = ld16_nt(xg + (((n * a.pH + hc) * a.pW + wc) * cols + col) * 16);
+      }
+    float dw[2][2][EPC];
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+      for (int dj = 0; dj < 2; ++dj) Elem<T>::unpack(dv[di][dj], dw[di][dj]);
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj) {
+        float xf[EPC], g[EPC], d[EPC];
+        Elem<T>::unpack(xv[pi][pj], xf);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+#pragma unroll
+        for (int di = 0; di <= pi; ++di)
+#pragma unroll
+          for (int dj = 0; dj <= pj; ++dj) {
+            const uint32_t code = (uint32_t)((pi - 2 * di + 1) * 3 + (pj - 2 * dj + 1));
+#pragma unroll
+            for (int e = 0; e < EPC; ++e)
+              if (wok[di][dj] && ((am[di][dj][e >> 2] >> (8 * (e & 3))) & 0xffu) == code) g[e] += dw[di][dj][e];
+          }
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          if (a.relu_from_x && !(fmaf(xf[e], cA[e], rsh[e]) > 0.f)) g[e] = 0.f;   // ReLU between the BatchNorm and the pool
+          d[e] = fmaf(cA[e], g[e], fmaf(cB[e], xf[e], cC[e]));
+        }
+        if (pok[pi][pj]) {
+          const size_t o = (((n * a.pH + 2 * bh + pi) * a.pW + 2 * bw + pj) * cols + col) * 16;
+          st16_nt(dxg + o, Elem<T>::pack(d));
+          if (a.gout) st16_nt(reinterpret_cast<char*>(a.gout) + o, Elem<T>::pack(g));
+        }
+      }
+  }
+}
+
 hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   const int epc = dtype == DT_BF16 ? 8 : 4;
   const int cols = a.C / epc;
@@ -442,6 +594,11 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   blocks = (blocks + 7) / 8;                              // >= 8 passes per block
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
+  if (a.pool_dy && a.pool_y) {
+    if (dtype == DT_BF16) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<float>, dim3((int)blocks), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   if (dtype == DT_BF16) {
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, st, a);
   } else {
@@ -451,6 +608,13 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st) {
+  if (a.pool_dy) {
+    const int epc = dtype == DT_BF16 ? 8 : 4;
+    const size_t items = (a.pixels / ((size_t)a.pH * a.pW)) * ((a.pH + 1) / 2) * ((a.pW + 1) / 2) * (a.C / epc);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<bf16_t>, dim3(ew_grid(items)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<float>, dim3(ew_grid(items)), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   if (dtype == DT_BF16) {
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(a.pixels * (a.C / 8))), dim3(256), 0, st, a);
   } else {

@@ -605,7 +605,7 @@ int heads_backward(sslcr_net* n, const float* dlogits, int npass, int N, bool ne
 
 // ---------------------------------------------------------------- backbone backward for one saved pass
 struct PoolSrc {            // gradient arriving through the stem max-pool (see sslcr_bn_bwd_desc.pool_dy)
-  const void* dy; const uint8_t* argmax; int H, W, OH, OW;
+  const void* dy; const uint8_t* argmax; int H, W, OH, OW; const void* y;
 };
 
 int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
@@ -615,7 +615,7 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.x = x; a.yact = yact; a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
   a.sums = c->bn_sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
-  if (pool) { a.pool_dy = pool->dy; a.pool_argmax = pool->argmax; a.pH = pool->H; a.pW = pool->W; a.pOH = pool->OH; a.pOW = pool->OW; }
+  if (pool) { a.pool_dy = pool->dy; a.pool_argmax = pool->argmax; a.pH = pool->H; a.pW = pool->W; a.pOH = pool->OH; a.pOW = pool->OW; a.pool_y = pool->y; }
   a.count = count * c->world;
   TRY(hipMemsetAsync(c->bn_sums, 0, 2 * bn.C * sizeof(double), st));
   TRY(launch_bn_bwd_reduce(c->dtype, a, st));
@@ -623,7 +623,8 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
   if (c->prof.on) {
     ProfRec r;
     r.e0 = c->prof.get(); r.e1 = c->prof.get();
-    r.name = c->dtype == DT_BF16 ? "sslcr::bn_bwd_apply_kernel<unsigned short>" : "sslcr::bn_bwd_apply_kernel<float>";
+    if (pool) r.name = c->dtype == DT_BF16 ? "sslcr::bn_bwd_apply_pool_kernel<unsigned short>" : "sslcr::bn_bwd_apply_pool_kernel<float>";
+    else r.name = c->dtype == DT_BF16 ? "sslcr::bn_bwd_apply_kernel<unsigned short>" : "sslcr::bn_bwd_apply_kernel<float>";
     r.flops = 0.0;
     // algorithmic bytes: read dy (or the 4x smaller pooled gradient + 1-byte argmax), x, (saved output for the ReLU mask); write dx (, g)
     const double t = (double)pixels * bn.C * c->esz();
@@ -760,7 +761,7 @@ int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pa
     // dOut (= dP, the pooled gradient) sits in one half of the scratch; dRaw0 goes to the other half.  The max-pool + ReLU
     // backward is folded into both BatchNorm-backward passes (the un-pooled gradient is never written out).
     char* dRaw0 = (dOut >= Bf) ? A : Bf;
-    PoolSrc pool{dOut, ps.argmax, d.oh0, d.ow0, d.ph, d.pw};
+    PoolSrc pool{dOut, ps.argmax, d.oh0, d.ow0, d.ph, d.pw, ps.pooled};
     const size_t spix = (size_t)N * d.oh0 * d.ow0;
     TRYI(bn_backward(n, n->bn0, ps.bn[0], nullptr, ps.raw0, nullptr, 1, dRaw0, nullptr, spix, (double)spix, st, &pool));
     if (n->rg[0]) {

@@ -203,11 +203,14 @@ def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, w
     g = torch.empty_like(x) if want_g else None
     d = L.BnBwdDesc(L.ptr(dy), L.ptr(x), L.ptr(yact), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(sums),
                     L.ptr(dx), L.ptr(g), pixels, Cn, int(relu_from_x), float(count if count is not None else pixels),
-                    None, None, 0, 0, 0, 0)
-    if pool is not None:          # pool = (pooled_dy [N,OH,OW,C], argmax u8): dy arrives through the stem max-pool
-        pdy, pam = pool
+                    None, None, 0, 0, 0, 0, None)
+    if pool is not None:          # pool = (pooled_dy [N,OH,OW,C], argmax u8[, pooled output y]): dy arrives through the stem max-pool
+        pdy, pam = pool[0], pool[1]
         _chk(pdy, pam)
         d.pool_dy, d.pool_argmax = L.ptr(pdy), L.ptr(pam)
+        if len(pool) > 2 and pool[2] is not None:
+            _chk(pool[2])
+            d.pool_y = L.ptr(pool[2])
         d.pH, d.pW, d.pOH, d.pOW = x.shape[1], x.shape[2], pdy.shape[1], pdy.shape[2]
     L.check(L.lib().sslcr_bn_bwd_reduce(_dt(x), d, L.stream_ptr()))
     L.check(L.lib().sslcr_bn_bwd_apply(_dt(x), d, L.stream_ptr()))

@@ -273,6 +273,28 @@ def test_bn_forward_chain(dtype):
         dx_b, sums_b, _ = K.bn_bwd(None, raw, sc, sh, mean, invstd, relu_from_x=True, pool=(to_dev(R.nhwc(dyp), dtype), am))
         close(dx_b, dx_a, 1e-5, "bn bwd through pool")
         close(sums_b, sums_a, 1e-6, "bn bwd sums through pool")
+        # with the saved pool OUTPUT the reduce pass works on pooled tensors only ((x - mean) recovered from y where y > 0)
+        dx_c, sums_c, _ = K.bn_bwd(None, raw, sc, sh, mean, invstd, relu_from_x=True,
+                                   pool=(to_dev(R.nhwc(dyp), dtype), am, pooled))
+        close(sums_c, sums_a, 1e-5, "bn bwd sums from pooled tensors")
+        close(dx_c, dx_a, 1e-5, "bn bwd through pool (pooled reduce)")
+        # a channel with gamma == 0 cannot be inverted: those lanes fetch x at the argmax position
+        sc0, sh0 = sc.clone(), sh.clone()
+        sc0[3] = 0.0; sh0[3] = 0.25; sc0[5] = 0.0; sh0[5] = -0.5
+        pooled0, am0 = K.bn_relu_maxpool(raw, sc0, sh0)
+        dxp0 = K.maxpool_relu_bwd(to_dev(R.nhwc(dyp), dtype), am0, raw, sc0, sh0)
+        dx_r, sums_r, _ = K.bn_bwd(dxp0, raw, sc0, sh0, mean, invstd)
+        dx_z, sums_z, _ = K.bn_bwd(None, raw, sc0, sh0, mean, invstd, relu_from_x=True,
+                                   pool=(to_dev(R.nhwc(dyp), dtype), am0, pooled0))
+        close(sums_z, sums_r, 1e-5, "bn bwd sums from pooled tensors, gamma == 0 channels")
+        close(dx_z, dx_r, 1e-5, "bn bwd through pool, gamma == 0 channels")
+    else:
+        # bf16: pooled-tensor reduce vs the gather form (same kernels as the engine's stem backward)
+        dyp = q(rnd(50, tuple(pooled.shape)), dtype)
+        dx_b, sums_b, _ = K.bn_bwd(None, raw, sc, sh, mean, invstd, relu_from_x=True, pool=(to_dev(dyp, dtype), am))
+        dx_c, sums_c, _ = K.bn_bwd(None, raw, sc, sh, mean, invstd, relu_from_x=True, pool=(to_dev(dyp, dtype), am, pooled))
+        close(sums_c, sums_b, 1e-2, "bn bwd sums from pooled tensors (bf16)")
+        close(dx_c, dx_b, 2e-2, "bn bwd through pool (pooled reduce, bf16)")
     dap = K.avgpool_bwd(ap, tuple(pooled.shape), dtype)
     close(dap, (ap / (pooled.shape[1] * pooled.shape[2]))[:, None, None, :].expand(pooled.shape), 1e-2 if dtype else 1e-6, "avgpool bwd")
 
