@@ -20,17 +20,36 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   const int i = tm * 16 + li, j = tn * 16 + li;
   const bool iv = i < M, jv = j < N;
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-  for (int kb = 0; kb < K; kb += 16) {
-    float a[4], b[4];
+  // 64 of K per trip: all 32 operand values are requested before the first MFMA (one k-step per trip left the wave waiting
+  // a full memory round trip per 4 MFMAs); operands contiguous in k are fetched as one 16-byte load per lane
+  const bool avec = sa_k == 1 && (sa_i & 3) == 0 && ((size_t)A & 15) == 0;
+  const bool bvec = sb_k == 1 && (sb_j & 3) == 0 && ((size_t)B & 15) == 0;
+  for (int kb = 0; kb < K; kb += 64) {
+    float a[4][4], b[4][4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int k = kb + 4 * g + e;
-      const bool kv = k < K;
-      a[e] = (iv && kv) ? A[(long)i * sa_i + (long)k * sa_k] : 0.f;
-      b[e] = (jv && kv) ? B[(long)k * sb_k + (long)j * sb_j] : 0.f;
+    for (int u = 0; u < 4; ++u) {
+      const int k0 = kb + 16 * u + 4 * g;
+      if (avec && iv && k0 + 3 < K) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(A + (long)i * sa_i + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[u][e] = v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[u][e] = (iv && k0 + e < K) ? A[(long)i * sa_i + (long)(k0 + e) * sa_k] : 0.f;
+      }
+      if (bvec && jv && k0 + 3 < K) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(B + (long)j * sb_j + k0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[u][e] = v[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[u][e] = (jv && k0 + e < K) ? B[(long)(k0 + e) * sb_k + (long)j * sb_j] : 0.f;
+      }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
   }
   // D[row = 4g + r][col = li]
   if (jv) {
