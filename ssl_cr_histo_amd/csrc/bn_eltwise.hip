@@ -15,7 +15,15 @@ __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const float* __rest
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
   double s = 0.0, ss = 0.0;
   if (c < C) {
-    for (int r = r0 + rl; r < r1; r += 8) {
+    int r = r0 + rl;
+    for (; r + 8 < r1; r += 16) {               // two rows in flight per trip
+      const float* p = part + (size_t)r * 2 * C;
+      const float* q = p + (size_t)16 * C;
+      const float a0 = p[c], a1 = p[C + c], b0 = q[c], b1 = q[C + c];
+      s += (double)a0 + (double)b0;
+      ss += (double)a1 + (double)b1;
+    }
+    for (; r < r1; r += 8) {
       const float* p = part + (size_t)r * 2 * C;
       s += (double)p[c];
       ss += (double)p[C + c];
@@ -80,7 +88,9 @@ hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
   double* stage = a.stage;
   int splits = 0;
   if (!a.sums_in) {
-    splits = a.rows >= 64 * SPLITS ? SPLITS : 1;
+    splits = a.rows / 32;                       // >= 4 dependent row loads per thread before it is worth another block row
+    if (splits > SPLITS) splits = SPLITS;
+    if (splits < 1) splits = 1;
     hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(cdiv(a.C, 32), splits), dim3(256), 0, st, a.partials, a.rows, a.C, stage, splits);
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a.C, 64)), dim3(64), 0, st, stage, splits, a);
