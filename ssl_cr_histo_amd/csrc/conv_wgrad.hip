@@ -210,8 +210,6 @@ hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t*
 const char* wgrad_kernel_name(int dtype, const WgradArgs& a) {
   const bool bf = dtype == DT_BF16;
   const int tw = wgrad_halo_tw(a);
-  const int pcb = wgrad_p_cb(dtype, a, tw);
-  if (pcb) return wgrad_p_name(tw, pcb);
   if (tw == 16) return bf ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 16>" : "sslcr::wgrad3x3_halo_kernel<float, 16>";
   if (tw == 8) return bf ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 8>" : "sslcr::wgrad3x3_halo_kernel<float, 8>";
   if (a.R == 3) return bf ? "sslcr::wgrad_kernel<unsigned short, 9>" : "sslcr::wgrad_kernel<float, 9>";
@@ -220,8 +218,6 @@ const char* wgrad_kernel_name(int dtype, const WgradArgs& a) {
 
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st) {
   const int tw = wgrad_halo_tw(a);
-  const int pcb = wgrad_p_cb(dtype, a, tw);
-  if (pcb) return launch_wgrad_p(a, tw, pcb, st);
   if (tw) return launch_wgrad_halo(dtype, a, tw, st);
   const bool three = a.R == 3;
   if (dtype == DT_BF16) return three ? launch_w<bf16_t, 9>(a, st) : launch_w<bf16_t, 1>(a, st);

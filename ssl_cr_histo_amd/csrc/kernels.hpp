@@ -49,10 +49,6 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 int wgrad_halo_tw(const WgradArgs& a);
 hipError_t launch_wgrad_halo(int dtype, const WgradArgs& a, int tw, hipStream_t st);
 hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, hipStream_t st);
-// wgrad_p.hip
-int wgrad_p_cb(int dtype, const WgradArgs& a, int tw);
-hipError_t launch_wgrad_p(const WgradArgs& a, int tw, int cb, hipStream_t st);
-const char* wgrad_p_name(int tw, int cb);
 // stem.hip
 hipError_t launch_stem(int dtype, const StemArgs& a, hipStream_t st);
 int stem_partials_rows(const StemArgs& a);
