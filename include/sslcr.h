@@ -180,6 +180,20 @@ typedef struct sslcr_pack_desc {
 int sslcr_pack_conv(int dtype, const sslcr_pack_desc* d, void* stream);
 int sslcr_pack_stem(int dtype, const sslcr_pack_desc* d, void* stream);
 
+/* ---- device-side weak augmentation ("next" row f1): TransformFix.weak = RandomHorizontalFlip() + RandomCrop(image_size)
+ *      (dataset.py:663-677), applied to a uint8 batch that is already in HBM.  The random draws stay on the host, in the
+ *      reference's order per sample (flip: torch.rand(1) < 0.5 ; crop: randint(0, SH-OH+1), randint(0, SW-OW+1)), so a run
+ *      is reproducible against the CPU transform; the kernel is the deterministic gather
+ *        dst[n][c][i][j] = src[n][c][top+i][flip ? SW-1-(left+j) : left+j]
+ *      writing the NCHW uint8 batch the stem ingests (eval_BreastPathQ_SSL_CR.py:68-74). */
+typedef struct sslcr_weak_aug_desc {
+  const uint8_t* src;     /* [N][3][SH][SW] (src_hwc=0) or [N][SH][SW][3] (src_hwc=1, the PIL/numpy layout) */
+  uint8_t* dst;           /* [N][3][OH][OW] */
+  const int32_t* params;  /* [N][3] device ints: flip (0/1), top, left */
+  int N, SH, SW, OH, OW, src_hwc;
+} sslcr_weak_aug_desc;
+int sslcr_weak_augment(const sslcr_weak_aug_desc* d, void* stream);
+
 /* ==================================================================================================
  * Engine: the whole ResNet18 TripletNet(_Finetune)+head graph, forward / backward / update, orchestrated
  * natively (one C call per step).  Replaces the step bodies of the reference's train()/validate():

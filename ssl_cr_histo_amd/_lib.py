@@ -55,6 +55,8 @@ TensorDesc = _S("TensorDesc", [("p", vp), ("g", vp), ("s1", vp), ("s2", vp), ("n
                                ("RS", i32)])
 OptDesc = _S("OptDesc", [("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("wd", f32),
                          ("momentum", f32), ("bc1", f32), ("bc2", f32), ("first_step", i32), ("grad_scale", f32)])
+WeakAugDesc = _S("WeakAugDesc", [("src", vp), ("dst", vp), ("params", vp)] +
+                 [(k, i32) for k in ("N", "SH", "SW", "OH", "OW", "src_hwc")])
 PackDesc = _S("PackDesc", [("w", vp), ("w_fwd", vp), ("w_dgrad", vp), ("gamma", vp), ("beta", vp), ("rmean", vp),
                            ("rvar", vp), ("eps", f32), ("bias_out", vp)] + [(k, i32) for k in ("K", "C", "R", "S", "dgrad_flip")])
 
@@ -88,6 +90,7 @@ SIGNATURES = {
     "sslcr_fill": (i32, [vp, sz, f32, vp]),
     "sslcr_pack_conv": (i32, [i32, P(PackDesc), vp]),
     "sslcr_pack_stem": (i32, [i32, P(PackDesc), vp]),
+    "sslcr_weak_augment": (i32, [P(WeakAugDesc), vp]),
 }
 
 _lib = None

@@ -149,6 +149,11 @@ int sslcr_pack_conv(int dtype, const sslcr_pack_desc* d, void* stream) {
   NEED(d && d->w && (d->w_fwd || d->w_dgrad), "null");
   return check(launch_pack_conv(dtype, *d, (hipStream_t)stream), "pack_conv");
 }
+int sslcr_weak_augment(const sslcr_weak_aug_desc* d, void* stream) {
+  NEED(d && d->src && d->dst && d->params, "null");
+  NEED(d->N > 0 && d->OH > 0 && d->OW > 0 && d->OH <= d->SH && d->OW <= d->SW, "crop larger than the source");
+  return check(launch_weak_augment(*d, (hipStream_t)stream), "weak_augment");
+}
 int sslcr_pack_stem(int dtype, const sslcr_pack_desc* d, void* stream) {
   DT_OK(dtype);
   NEED(d && d->w && d->w_fwd && d->K == 64 && d->C == 3 && d->R == 7 && d->S == 7, "stem shape");

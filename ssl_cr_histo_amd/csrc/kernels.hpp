@@ -69,6 +69,8 @@ hipError_t launch_linear_fwd(const float* x, const float* w, const float* b, flo
 hipError_t launch_linear_bwd(const float* x, const float* w, const float* dy, const float* yact, float* dx, float* dw, float* db,
                              int M, int N, int K, int dx_accumulate, float* scratch, hipStream_t st);
 hipError_t launch_loss(const LossArgs& a, hipStream_t st);
+// augment.hip
+hipError_t launch_weak_augment(const sslcr_weak_aug_desc& a, hipStream_t st);
 // optim.hip
 hipError_t launch_optimizer(const TensorDesc* d_descs, int ntensors, int max_n, const OptArgs& o, hipStream_t st);
 hipError_t launch_axpby(float* p, float* q, size_t n, float alpha, int copy_back, hipStream_t st);

@@ -89,3 +89,21 @@ def test_script_modules_expose_reference_names():
         "unlabeled_train_loader", "optimizer", "epoch"]
     assert list(inspect.signature(steps.rsp_train).parameters) == ["args", "model", "classifier", "train_loader", "criterion",
                                                                    "optimizer", "epoch"]
+
+
+def test_weak_augment_params_follow_the_reference_draw_order():
+    """'next' row f1 host side: per sample flip = rand(1) < p, then randint(top), randint(left); no crop draws when the
+    source already has the target size (RandomCrop.get_params).  Checked against the oracle's restatement."""
+    import pytest
+    from oracle import augment_ref as AR
+    from ssl_cr_histo_amd import augment as A
+    for n, hw, size in ((7, (300, 280), 256), (4, (64, 64), 64), (3, (40, 52), (30, 32))):
+        g1, g2 = torch.Generator().manual_seed(11), torch.Generator().manual_seed(11)
+        p1, p2 = A.weak_params(n, hw, size, g1), AR.draw_params(n, hw, size, g2)
+        assert p1.dtype == torch.int32 and torch.equal(p1, p2)
+        th, tw = (size, size) if isinstance(size, int) else size
+        assert int(p1[:, 1].max()) <= hw[0] - th and int(p1[:, 2].max()) <= hw[1] - tw and int(p1.min()) >= 0
+        # the generators are left in the same state: the NEXT draw agrees too
+        assert torch.equal(torch.rand(3, generator=g1), torch.rand(3, generator=g2))
+    with pytest.raises(ValueError):
+        A.weak_params(1, (32, 32), 64)

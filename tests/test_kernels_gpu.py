@@ -420,3 +420,24 @@ def test_optimizer_and_pack(kind):
     L.check(L.lib().sslcr_axpby(L.ptr(a), L.ptr(b2), 64, 0.3, 1, L.stream_ptr()))
     close(a, ref_a, 1e-6, "axpby")
     assert torch.equal(a, b2)
+
+
+@pytest.mark.parametrize("hwc", [False, True])
+@pytest.mark.parametrize("shape", [(5, 300, 300, 256), (3, 40, 52, 30), (4, 64, 64, 64)])   # incl. OW % 4 != 0 and no-crop
+def test_weak_augment(shape, hwc):
+    """'next' row f1: device-side TransformFix.weak vs the oracle's flip-then-crop on the same host-drawn parameters."""
+    from oracle import augment_ref as AR
+    from ssl_cr_histo_amd import augment as A
+    N, SH, SW, S = shape
+    src = torch.from_numpy(np.random.RandomState(77).randint(0, 256, (N, 3, SH, SW), dtype=np.uint8))
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    prm = A.weak_params(N, (SH, SW), S, g1)
+    assert torch.equal(prm, AR.draw_params(N, (SH, SW), S, g2))
+    # extreme offsets too
+    prm[0] = torch.tensor([1, SH - S, SW - S], dtype=torch.int32)
+    prm[1] = torch.tensor([0, 0, SW - S], dtype=torch.int32)
+    want = AR.weak_batch(src, prm, S)
+    dev_src = (src.permute(0, 2, 3, 1).contiguous() if hwc else src).to(DEV)
+    got = A.weak_augment(dev_src, prm, S, src_hwc=hwc)
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (N, 3, S, S)
+    assert torch.equal(got.cpu(), want)
