@@ -43,6 +43,9 @@ CASES = {
     "cam_sup": dict(script="cam_sup", hw=64, b=2, nb=2, modules=0, classes=2, lr=1e-3, wd=1e-4, opt="sgd"),
     # eval_BreastPathQ_SSL.train: supervised MSE, Adam (:396); image side is args.image_size (:58)
     "bpq_sup": dict(script="bpq_sup", hw=64, b=2, nb=2, modules=0, classes=1, lr=1e-3, wd=1e-4, opt="adam"),
+    # test_Camelyon16.test: forward-only WSI tile classification -> tumour-probability map ("next" row f3); the loader
+    # yields (float32 RGB tile batch, x_mask, y_mask) for the tissue pixels of a mask, last batch ragged (:41-66)
+    "cam_wsi": dict(script="cam_wsi", hw=64, b=4, classes=2, mask=(6, 5)),
 }
 
 PARAM_SEED = 42        # the reference's default --seed (eval_BreastPathQ_SSL_CR.py:253)
@@ -98,3 +101,34 @@ def val_batches_cls(case, seed0, label):
     c = CASES[case]
     return [(u8(seed0 + i, (2, 3, c["hw"], c["hw"])), torch.full((2,), label, dtype=torch.int64))
             for i in range(2)]
+
+
+class WsiLoader:
+    """What test_Camelyon16.test() needs of its DataLoader: iteration over (input, x_mask, y_mask) batches, ``len``, and
+    ``.dataset.mask`` (the tissue mask whose shape the probability map takes; dataset.py:958-972)."""
+
+    def __init__(self, mask, batches):
+        self.dataset = type("WsiDataset", (), {"mask": mask})()
+        self._batches = batches
+
+    def __iter__(self):
+        return iter(self._batches)
+
+    def __len__(self):
+        return len(self._batches)
+
+
+def wsi_loader(case="cam_wsi", seed0=6000):
+    """seeded tissue mask + tile batches in the order DatasetCamelyon16_test enumerates them (np.where(mask), row-major);
+    tiles are float32 RGB 0..255 like ``np.array(img, dtype=np.float32).transpose(2,0,1)`` (dataset.py:991-993)."""
+    c = CASES[case]
+    rs = np.random.RandomState(seed0)
+    mask = rs.rand(*c["mask"]) < 0.45
+    mask[0, 0] = True                           # at least one tissue pixel, and an edge one
+    xs, ys = np.where(mask)
+    batches = []
+    for i in range(0, len(xs), c["b"]):
+        n = min(c["b"], len(xs) - i)
+        tiles = u8(seed0 + 10 + i, (n, 3, c["hw"], c["hw"])).float()
+        batches.append((tiles, torch.from_numpy(xs[i:i + n].copy()), torch.from_numpy(ys[i:i + n].copy())))
+    return WsiLoader(mask, batches)

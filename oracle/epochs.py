@@ -86,6 +86,20 @@ def kather_cr_validate(ps, bs, val_loader, faithful=True):
     return losses.avg, acc.avg
 
 
+def cam_wsi_test(p, b, test_loader, faithful=True):
+    """test_Camelyon16.py:30-70 -> probs_map (float64, shape of the tissue mask): eval forward, softmax, last column
+    ('tumor'), scattered to the mask coordinates of each tile."""
+    import numpy as np
+    probs_map = np.zeros(test_loader.dataset.mask.shape)
+    for inp, x_mask, y_mask in test_loader:
+        with torch.no_grad():
+            feats = S.M.finetune_forward(p, b, inp, False, faithful)
+            output = S.M.classifier_forward(p, feats)
+            probs = torch.softmax(output, dim=1)[:, -1]
+        probs_map[x_mask.numpy(), y_mask.numpy()] = probs.numpy()
+    return probs_map
+
+
 def rsp_epoch(p, b, opt, loader, tile, train=True):
     losses, acc = S.AverageMeter(), S.AverageMeter()
     feats, targets = [], []

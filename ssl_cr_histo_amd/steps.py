@@ -317,6 +317,26 @@ def kather_sup_train(args, model, classifier, train_loader, criterion, optimizer
     return m["loss"].avg, m["acc"].avg
 
 
+# ------------------------------------------------------------------------------------------------ WSI inference (f3)
+def camelyon16_test(args, model, classifier, test_loader):
+    """test_Camelyon16.test (test_Camelyon16.py:30-70) -> probs_map: every tissue pixel of ``test_loader.dataset.mask``
+    gets the softmax 'tumor' probability of its tile; forward-only (BatchNorm folded, all epilogues fused)."""
+    import numpy as np
+    eng = get_engine(_device_of(model))
+    model.eval()
+    classifier.eval()
+    net = eng.bind(model, classifier)
+    probs_map = np.zeros(test_loader.dataset.mask.shape)
+    t0 = time.time()
+    for batch_idx, (input, x_mask, y_mask) in enumerate(test_loader):
+        _, output = net.forward((input,), train=False)
+        probs = torch.softmax(output, dim=1)[:, -1].cpu().numpy()           # second column 'tumor' (:58-60)
+        probs_map[x_mask.numpy(), y_mask.numpy()] = probs
+        if (batch_idx + 1) % 10 == 0 and getattr(args, "print_freq", 0):
+            print("Test: [{0}/{1}]\tBT {2:.3f}".format(batch_idx, _len(test_loader), (time.time() - t0) / (batch_idx + 1)))
+    return probs_map
+
+
 def teacher_refresh(model_teacher, classifier_teacher, model_student, classifier_student, ema_decay=0.0):
     """In-place form of the reference's per-epoch ``teacher = copy.deepcopy(student)`` (eval_BreastPathQ_SSL_CR.py:515-516),
     generalised to an EMA (decay 0 == the reference).  ``copy.deepcopy`` itself also works on these modules."""

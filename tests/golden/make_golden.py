@@ -221,6 +221,16 @@ def gen_bpq_sup(name, out):
     snapshot(name, ms, cs, out)
 
 
+def gen_cam_wsi(name, out):
+    """test_Camelyon16.test(): forward-only tile classification -> probability map ("next" row f3)."""
+    m = importlib.import_module("test_Camelyon16")
+    model, cls = build("finetune", "finetune", 2, rand_stats=True)
+    loader = C.wsi_loader(name)
+    pm = m.test(args_ns(), model, cls, loader)
+    out[f"{name}/ret"] = np.asarray(pm, dtype=np.float64)
+    out[f"{name}/mask"] = loader.dataset.mask
+
+
 def gen_stages(out):
     """G3: per-stage activations of the reference TripletNet_Finetune backbone, N=2, 64x64."""
     for mode in ("eval", "train"):
@@ -249,7 +259,8 @@ def gen_stages(out):
 
 def main():
     gens = {"bpq_cr_f60": gen_bpq_cr, "bpq_cr_f0": gen_bpq_cr, "cam_cr_f60": gen_cam_cr, "cam_cr_f0": gen_cam_cr,
-            "kather_cr_f0": gen_kather_cr, "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup}
+            "kather_cr_f0": gen_kather_cr, "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup,
+            "cam_wsi": gen_cam_wsi}
     only = sys.argv[1:]
     for name, fn in gens.items():
         if only and name not in only:
@@ -257,7 +268,7 @@ def main():
         out = {}
         fn(name, out)
         np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
-        print("wrote", name, out[f"{name}/ret"])
+        print("wrote", name, out[f"{name}/ret"] if out[f"{name}/ret"].size < 16 else out[f"{name}/ret"].shape)
     if not only or "stages" in only:
         out = {}
         gen_stages(out)

@@ -151,6 +151,24 @@ def test_cam_cr_epoch_vs_reference(name, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_cam_wsi_probability_map_vs_reference(dtype):
+    """'next' row f3: forward-only WSI tile classification (test_Camelyon16.test) against the reference's own map."""
+    from ssl_cr_histo_amd.scripts import test_Camelyon16 as script
+    _engine(dtype)
+    name = "cam_wsi"
+    g = load_golden(name)
+    model, cls = build("finetune", "finetune", 2, True)
+    loader = C.wsi_loader(name)
+    pm = script.test(ns(), model, cls, loader)
+    want = g[f"{name}/ret"]
+    assert pm.shape == want.shape and pm.dtype == np.float64
+    assert np.array_equal(pm == 0, ~g[f"{name}/mask"])
+    # probabilities in [0,1]: absolute tolerance.  fp32 mode 1e-3 of the logit scale; bf16 measured, not 1e-3
+    tol = 1e-3 if dtype == "fp32" else 6e-2
+    assert np.abs(pm - want).max() <= tol, np.abs(pm - want).max()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_kather_cr_epoch_vs_reference(dtype):
     from ssl_cr_histo_amd import steps
     _engine(dtype)

@@ -1,6 +1,7 @@
 """Pin the CPU oracle (oracle/) against the golden vectors captured from the REFERENCE's own
 train()/validate() (tests/golden/make_golden.py).  CPU only."""
 import pytest
+import numpy as np
 import torch
 
 from oracle import cases as C
@@ -131,6 +132,20 @@ def test_supervised():
     assert abs(ret[0] - g[f"{name}/ret"][0]) <= RT * g[f"{name}/ret"][0]
     assert rel_err(ret[1], g[f"{name}/feats"]) < RT
     check_snapshot(g, name, snapshot_dict(p, bn), RT)
+
+
+def test_cam_wsi_probability_map():
+    """'next' row f3: the oracle's restatement of test_Camelyon16.test() against the map the reference itself produced."""
+    name = "cam_wsi"
+    g = load_golden(name)
+    pn, bn, pc = oracle_state("finetune", 2, True)
+    loader = C.wsi_loader(name)
+    assert np.array_equal(loader.dataset.mask, g[f"{name}/mask"])
+    for faithful in (True, False):
+        pm = E.cam_wsi_test(merged(pn, pc), bn, loader, faithful)
+        assert pm.shape == g[f"{name}/ret"].shape and pm.dtype == np.float64
+        assert np.array_equal(pm == 0, ~g[f"{name}/mask"])                 # untouched where there is no tissue
+        assert np.abs(pm - g[f"{name}/ret"]).max() <= 1e-5
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
