@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--image_size", type=int, default=256)
     ap.add_argument("--modules_student", type=int, default=0, help="0 = full fine-tune (headline); 60 = reference default freeze")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--bn-sync", type=int, default=1, choices=[0, 1],
+                    help="N>1: 1 = train-mode BatchNorm on global-batch statistics (RCCL all-reduce of per-channel sums, the "
+                         "north-star form); 0 = per-replica statistics like the reference's nn.DataParallel (gradient buckets only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -118,6 +121,7 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
     eng = E.set_engine(E.Engine(device, args.dtype))
     sdist.attach_engine(eng)
+    eng.set_bn_sync(bool(args.bn_sync))
 
     hw, b, mu = args.image_size, args.batch_size, args.mu
     lr, wd = 1e-4, 1e-4
@@ -150,7 +154,8 @@ def main():
         flops_step = nu * F_FWD + (nx + nu) * (F_FWD + (F_BWD_FULL if args.modules_student == 0 else 0))
         cfg = {"workload": f"eval_BreastPathQ_SSL_CR.train step, per-GPU --batch_size {b} --mu {mu}: student {nx}+{nu}, teacher {nu} "
                            f"({patches} distinct {hw}x{hw} uint8 patches/step/GPU), modules_student={args.modules_student}, Adam",
-               "global_batch_patches": patches * world, "parallelism": f"dp{world}", "backward": bwd}
+               "global_batch_patches": patches * world, "parallelism": f"dp{world}", "backward": bwd,
+               "bn_sync": bool(args.bn_sync) if world > 1 else None}
     elif args.workload == "fwd":
         n = 4 * b
         ms, cs = build_nets(args, device)

@@ -211,6 +211,9 @@ int sslcr_destroy(sslcr_ctx* ctx);
  * reference (the reference's nn.DataParallel BN is per-replica, eval_BreastPathQ_SSL_CR.py:474-477). */
 int sslcr_comm_unique_id(void* id256);       /* two 128-byte RCCL ids: [0] BatchNorm sums (compute stream), [1] gradient buckets (side stream) */
 int sslcr_comm_init(sslcr_ctx* ctx, const void* id256, int rank, int world);
+/* on (default): synced BatchNorm as described above.  off: every rank normalises with its own shard's statistics -- the
+ * semantics of the reference's nn.DataParallel replicas -- and only the gradient buckets are exchanged. */
+int sslcr_set_bn_sync(sslcr_ctx* ctx, int on);
 
 /* measurement: bracket every conv launch of this ctx with HIP events on its own stream (bench.py roofline leg).
  * which = 0: conv_igemm (forward + dgrad), 1: wgrad.  out4 = {launches, total ms, algorithmic FLOPs, algorithmic bytes}.

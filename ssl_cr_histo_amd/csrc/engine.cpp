@@ -120,6 +120,7 @@ struct sslcr_ctx {
   ncclComm_t comm_g = nullptr;    // gradient buckets, only ever used on comm_stream (one communicator per stream, like
                                   // separate process groups: no cross-stream serialisation inside RCCL)
   int rank = 0, world = 1;
+  int bn_sync = 1;                // train-mode BatchNorm on GLOBAL batch statistics (all-reduce of per-channel sums); 0 = per replica
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_ready[8], ev_done = nullptr;
   DevBuf scratch;     // eval-forward activations and backward transients (never live at the same time)
@@ -322,7 +323,7 @@ int finalize_bn(sslcr_net* n, const BnL& bn, const float* partials, int rows, do
   a.running_mean = n->bn_rm[bn.bidx]; a.running_var = n->bn_rv[bn.bidx]; a.num_batches_tracked = n->bn_nbt[bn.bidx];
   a.momentum = 0.1f; a.eps = 1e-5f; a.replay = replay;
   a.stage = c->bn_stage;
-  if (c->comm) {
+  if (c->comm && c->bn_sync) {
     // global-batch statistics: reduce rows -> [2][C] sums, all-reduce, finalize from the sums
     BnFinalizeArgs r = a;
     r.sums_out = c->bn_sums;
@@ -616,10 +617,11 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
   a.dy = dy; a.x = x; a.yact = yact; a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
   a.sums = c->bn_sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
   if (pool) { a.pool_dy = pool->dy; a.pool_argmax = pool->argmax; a.pH = pool->H; a.pW = pool->W; a.pOH = pool->OH; a.pOW = pool->OW; a.pool_y = pool->y; }
-  a.count = count * c->world;
+  const bool synced = c->comm && c->bn_sync;
+  a.count = synced ? count * c->world : count;
   TRY(hipMemsetAsync(c->bn_sums, 0, 2 * bn.C * sizeof(double), st));
   TRY(launch_bn_bwd_reduce(c->dtype, a, st));
-  if (c->comm) TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
+  if (synced) TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
   if (c->prof.on) {
     ProfRec r;
     r.e0 = c->prof.get(); r.e1 = c->prof.get();
@@ -643,7 +645,8 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
     float* dg = gptr(n, bn.pg);
     float* db = gptr(n, bn.pb);
     // synced BN: every rank holds the GLOBAL sums and the gradient all-reduce adds `world` copies -> pre-divide
-    if (dg && db) TRY(launch_bn_param_grads_scaled(c->bn_sums, sv.invstd, dg, db, bn.C, 1.0f / c->world, st));
+    // (per-replica BN: the sums are this rank's share, the gradient all-reduce adds them up)
+    if (dg && db) TRY(launch_bn_param_grads_scaled(c->bn_sums, sv.invstd, dg, db, bn.C, synced ? 1.0f / c->world : 1.0f, st));
   }
   return 0;
 }
@@ -908,6 +911,12 @@ int sslcr_comm_unique_id(void* id256) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   TRYN(ncclGetUniqueId((ncclUniqueId*)id256));
   TRYN(ncclGetUniqueId((ncclUniqueId*)((char*)id256 + 128)));
+  return 0;
+}
+
+int sslcr_set_bn_sync(sslcr_ctx* c, int on) {
+  if (!c) return fail("sslcr_set_bn_sync: null");
+  c->bn_sync = on ? 1 : 0;
   return 0;
 }
 

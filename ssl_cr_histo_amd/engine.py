@@ -35,6 +35,7 @@ _ENGINE_SIGS = {
     "sslcr_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "sslcr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "sslcr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "sslcr_set_bn_sync": (C.c_int, [C.c_void_p, C.c_int]),
     "sslcr_net_create": (C.c_int, [C.c_void_p, C.POINTER(SslcrNetDesc), C.POINTER(C.c_void_p)]),
     "sslcr_net_destroy": (C.c_int, [C.c_void_p]),
     "sslcr_net_set_requires_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
@@ -255,6 +256,11 @@ class Engine:
         idbuf = (C.c_char * 256).from_buffer_copy(raw)
         L.check(L.lib().sslcr_comm_init(self.handle, idbuf, rank, world))
         self.rank, self.world = rank, world
+
+    def set_bn_sync(self, on):
+        """True (default): train-mode BatchNorm uses global-batch statistics across ranks; False: per-replica statistics
+        like the reference's nn.DataParallel (eval_BreastPathQ_SSL_CR.py:474-477)."""
+        L.check(L.lib().sslcr_set_bn_sync(self.handle, int(bool(on))))
 
     def _reduce_losses(self, losses):
         """logging only: each rank's (loss, loss_x, loss_u) is already scaled by 1/global-count and #correct is a count,

@@ -383,6 +383,7 @@ import test_engine_gpu as T
 eng = E.set_engine(E.Engine("cuda:0", "fp32"))
 if os.environ.get("SSLCR_COMM_SELFTEST"):
     eng.init_comm(0, 1, lambda b: b)
+    eng.set_bn_sync(os.environ.get("SELFTEST_BN_SYNC", "1") == "1")
 mt, ct = T.build("finetune", "finetune", 2, True); ms, cs = T.build("finetune", "finetune", 2, True)
 T.freeze(mt, 64); mt.eval(); ms.train()
 te, st = eng.bind(mt, ct), eng.bind(ms, cs)
@@ -396,15 +397,17 @@ print("RESULT", " ".join(f"{v:.7e}" for v in r["losses"].cpu().tolist()), f"{flo
       f"{float(dict(ms.named_parameters())['model.layer4.1.bn2.weight'].double().sum()):.9e}")
 '''
     outs = []
-    for flag in ("", "1"):
+    for flag in ("", "1", "per-replica"):          # plain ; communicators + synced BN ; communicators + per-replica BN
         env = dict(os.environ)
         env.pop("SSLCR_COMM_SELFTEST", None)
         if flag:
             env["SSLCR_COMM_SELFTEST"] = "1"
+            env["SELFTEST_BN_SYNC"] = "0" if flag == "per-replica" else "1"
         p = subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                            capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")][-1]
         outs.append([float(v) for v in line.split()[1:]])
-    for a, b in zip(*outs):
-        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), outs
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), outs
