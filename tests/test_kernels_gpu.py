@@ -228,10 +228,11 @@ def test_stem(shape, in_u8, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
-def test_bn_forward_chain(dtype):
+@pytest.mark.parametrize("hw", [(16, 16), (15, 13)])          # odd sizes: ragged 2x2 blocks / pooling windows at the border
+def test_bn_forward_chain(hw, dtype):
     """conv stats -> finalize (x3 replay) -> bn_act / pool, against F.batch_norm train mode."""
     K = _k()
-    N, H, W, C = 4, 16, 16, 64
+    N, (H, W), C = 4, hw, 64
     x = q(rnd(41, (N, H, W, C), 3.0) + 1.5, dtype)
     w = q(rnd(42, (C, 3, 3, C), 0.05), dtype)
     gamma, beta = rnd(43, (C,)).abs() + 0.5, rnd(44, (C,))
