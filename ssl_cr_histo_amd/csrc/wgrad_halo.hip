@@ -283,7 +283,7 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
   int splits = cdiv(2 * cus, kc);
-  const int max_splits = cdiv(ntiles, 2);                 // at least 2 tiles (256 pixels) per workgroup
+  const int max_splits = cdiv(ntiles, 16);                // at least 16 tiles per workgroup: below that the fp32 atomics of its 64x64x9 block outweigh the parallelism (RSP N=128: +4 % step)
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const int tps = cdiv(ntiles, splits);
