@@ -76,6 +76,9 @@ typedef struct sslcr_stem_desc {
   const float* bias;      /* [64] or NULL */
   float* stats;           /* [sslcr_stem_partial_rows][2][64] or NULL */
   int N, H, W, OH, OW, in_f32, relu;
+  const void* x2;         /* optional second input segment: images n >= n_split are read from x2[n - n_split] -- the
+                             reference's torch.cat((inputs_x, inputs_u_s)) (eval_BreastPathQ_SSL_CR.py:82) without the copy */
+  int n_split;
 } sslcr_stem_desc;
 int sslcr_stem_conv(int dtype, const sslcr_stem_desc* d, void* stream);
 int sslcr_stem_partial_rows(const sslcr_stem_desc* d);
@@ -83,6 +86,7 @@ typedef struct sslcr_stem_wgrad_desc {
   const void* x; const void* dy;
   float* dw;              /* [64][3][7][7] fp32 (PyTorch layout), accumulated */
   int N, H, W, OH, OW, in_f32;
+  const void* x2; int n_split;   /* as in sslcr_stem_desc */
 } sslcr_stem_wgrad_desc;
 int sslcr_stem_wgrad(int dtype, const sslcr_stem_wgrad_desc* d, void* stream);
 
@@ -269,6 +273,8 @@ typedef struct sslcr_ssl_cr_desc {
   float* logits_t;          /* [nu,C] out */
   float* losses;            /* [4] out: loss, loss_x, loss_u, #correct */
   int backward;
+  const void* x_student2;   /* optional: then x_student holds only the nx labeled images and x_student2 the nu strong-augmented
+                               unlabeled ones (the concatenation of :82 happens in the stem kernel's addressing) */
 } sslcr_ssl_cr_desc;
 int sslcr_step_ssl_cr(sslcr_net* teacher, sslcr_net* student, const sslcr_ssl_cr_desc* d, void* stream);
 

@@ -30,9 +30,9 @@ ConvDesc = _S("ConvDesc", [("x", vp), ("w", vp), ("y", vp), ("in_scale", vp), ("
 WgradDesc = _S("WgradDesc", [("x", vp), ("dy", vp), ("dw", vp), ("in_scale", vp), ("in_shift", vp), ("in_relu", i32)] +
                [(k, i32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW")])
 StemDesc = _S("StemDesc", [("x", vp), ("w", vp), ("y", vp), ("bias", vp), ("stats", vp)] +
-              [(k, i32) for k in ("N", "H", "W", "OH", "OW", "in_f32", "relu")])
+              [(k, i32) for k in ("N", "H", "W", "OH", "OW", "in_f32", "relu")] + [("x2", vp), ("n_split", i32)])
 StemWgradDesc = _S("StemWgradDesc", [("x", vp), ("dy", vp), ("dw", vp)] +
-                   [(k, i32) for k in ("N", "H", "W", "OH", "OW", "in_f32")])
+                   [(k, i32) for k in ("N", "H", "W", "OH", "OW", "in_f32")] + [("x2", vp), ("n_split", i32)])
 BnFinalizeDesc = _S("BnFinalizeDesc", [("partials", vp), ("rows", i32), ("C", i32), ("count", f64), ("gamma", vp),
                                        ("beta", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("invstd", vp),
                                        ("running_mean", vp), ("running_var", vp), ("num_batches_tracked", vp),

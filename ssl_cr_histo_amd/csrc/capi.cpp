@@ -62,12 +62,14 @@ int sslcr_stem_conv(int dtype, const sslcr_stem_desc* d, void* stream) {
   DT_OK(dtype);
   NEED(d && d->x && d->w && d->y, "null tensor");
   NEED(d->OH == (d->H + 6 - 7) / 2 + 1 && d->OW == (d->W + 6 - 7) / 2 + 1, "7x7/2 pad 3 output dims");
+  NEED(!d->x2 || (d->n_split >= 0 && d->n_split <= d->N), "n_split outside the batch");
   return check(launch_stem(dtype, *d, (hipStream_t)stream), "stem_conv");
 }
 int sslcr_stem_partial_rows(const sslcr_stem_desc* d) { return d ? stem_partials_rows(*d) : -1; }
 int sslcr_stem_wgrad(int dtype, const sslcr_stem_wgrad_desc* d, void* stream) {
   DT_OK(dtype);
   NEED(d && d->x && d->dy && d->dw, "null tensor");
+  NEED(!d->x2 || (d->n_split >= 0 && d->n_split <= d->N), "n_split outside the batch");
   return check(launch_stem_wgrad(dtype, *d, (hipStream_t)stream), "stem_wgrad");
 }
 

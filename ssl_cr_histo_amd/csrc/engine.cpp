@@ -82,6 +82,8 @@ struct BnSaved {
 };
 struct PassState {
   const void* x = nullptr;
+  const void* x2 = nullptr;      // second input segment (images n >= n_split), see sslcr_stem_desc
+  int n_split = 0;
   int in_f32 = 0, N = 0, H = 0, W = 0;
   DevBuf mem;
   char* raw0 = nullptr;
@@ -134,6 +136,8 @@ struct sslcr_ctx {
 
 struct sslcr_net {
   sslcr_ctx* ctx = nullptr;
+  const void* split_x2 = nullptr;   // set by sslcr_step_ssl_cr around the student pass: input = (x[0:split_n], split_x2)
+  int split_n = 0;
   int nparams = 0, head_kind = 0, ncls = 1, triplet = 0;
   std::vector<float*> params;
   std::vector<uint8_t> rg;
@@ -410,11 +414,12 @@ int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f3
   const int dt = c->dtype;
   if (ps.N != N || ps.H != H || ps.W != W || !ps.mem.p) TRYI(alloc_pass(n, ps, N, H, W));
   ps.x = x; ps.in_f32 = in_f32;
+  ps.x2 = n->split_x2; ps.n_split = n->split_x2 ? n->split_n : 0;
   const Dims d = make_dims(H, W);
   {
     StemArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.w = n->stem.w_fwd; a.y = ps.raw0;
+    a.x = x; a.x2 = ps.x2; a.n_split = ps.n_split; a.w = n->stem.w_fwd; a.y = ps.raw0;
     a.N = N; a.H = H; a.W = W; a.OH = d.oh0; a.OW = d.ow0; a.in_f32 = in_f32;
     const int rows = stem_partials_rows(a);
     TRYI(c->partials.ensure((size_t)rows * 2 * 64 * sizeof(float)));
@@ -770,7 +775,7 @@ int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pa
     if (n->rg[0]) {
       StemWgradArgs w;
       memset(&w, 0, sizeof(w));
-      w.x = ps.x; w.dy = dRaw0; w.dw = (float*)n->grads.p + n->goff[0];
+      w.x = ps.x; w.x2 = ps.x2; w.n_split = ps.n_split; w.dy = dRaw0; w.dw = (float*)n->grads.p + n->goff[0];
       w.N = N; w.H = ps.H; w.W = ps.W; w.OH = d.oh0; w.OW = d.ow0; w.in_f32 = ps.in_f32;
       TRY(launch_stem_wgrad(dt, w, st));
     }
@@ -1106,7 +1111,11 @@ int sslcr_step_ssl_cr(sslcr_net* te, sslcr_net* stn, const sslcr_ssl_cr_desc* d,
   TRYI(net_forward(te, 0, xt, d->in_f32, d->nu, d->H, d->W, nullptr, stn->logits_t, st));
   // student: train mode on cat(x, u_s) (:82-84)
   const void* xs[3] = {d->x_student, nullptr, nullptr};
-  TRYI(net_forward(stn, 1, xs, d->in_f32, Ns, d->H, d->W, d->feats, d->logits, st));
+  if (d->x_student2 && stn->triplet) return fail("sslcr_step_ssl_cr: split student input needs a single-branch net");
+  stn->split_x2 = d->x_student2; stn->split_n = d->nx;
+  const int frc = net_forward(stn, 1, xs, d->in_f32, Ns, d->H, d->W, d->feats, d->logits, st);
+  stn->split_x2 = nullptr; stn->split_n = 0;
+  if (frc) return frc;
   LossArgs L;
   memset(&L, 0, sizeof(L));
   L.kind = d->kind; L.logits = stn->logits; L.logits_t = stn->logits_t; L.target_f = d->target_f; L.target_i = d->target_i;

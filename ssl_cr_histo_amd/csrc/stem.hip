@@ -46,6 +46,12 @@ __device__ __forceinline__ void stem_load_halo(T* halo, const void* xv, int n, i
 // 64-byte segments (16 consecutive channels per lane would leave every 16-byte store half of a 32-byte stride)
 #define STEM_CH(t, q, j) ((((t) >> 1) * 32) + ((q) * 8) + (((t) & 1) * 4) + (j))
 constexpr int STEM_NEL = (3 * HR * HC + 255) / 256;     // 10 values per thread
+// Image n of a (possibly two-segment) input batch: the reference's torch.cat((inputs_x, inputs_u_s)) is an address select here.
+template <typename A>
+__device__ __forceinline__ const void* stem_seg(const A& a, int& n) {
+  if (a.x2 && n >= a.n_split) { n -= a.n_split; return a.x2; }
+  return a.x;
+}
 template <bool INF32>
 __device__ __forceinline__ void stem_issue(float (&pv)[STEM_NEL], const int (&role)[STEM_NEL], const void* xv, int n, int H, int W,
                                            int hi0, int wi0) {
@@ -156,11 +162,13 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
   if ((int)blockIdx.x < ntiles) {
     const int t0 = blockIdx.x;
     const int n = t0 / (tiles_h * tiles_w), rem = t0 - n * tiles_h * tiles_w;
+    int ns = n;
+    const void* xseg = stem_seg(a, ns);
     if (fast) {
-      raw = stem_issue4(a.x, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
+      raw = stem_issue4(xseg, ns, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
       stem_commit4<T>(halo0, raw);
     } else {
-      stem_issue<INF32>(pv, role, a.x, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
+      stem_issue<INF32>(pv, role, xseg, ns, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
       stem_commit<T>(halo0, pv, role);
     }
   }
@@ -179,9 +187,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
     const T* halo = halo0 + cur * (HR * HC * 4);
     const int nxt = tile + gridDim.x;
     if (nxt < ntiles) {
-      const int nn = nxt / (tiles_h * tiles_w), nrem = nxt - nn * tiles_h * tiles_w;
-      if (fast) raw = stem_issue4(a.x, nn, a.H, a.W, 2 * (nrem / tiles_w) * TH - 3, 2 * (nrem % tiles_w) * TW - 3);
-      else stem_issue<INF32>(pv, role, a.x, nn, a.H, a.W, 2 * (nrem / tiles_w) * TH - 3, 2 * (nrem % tiles_w) * TW - 3);
+      int nn = nxt / (tiles_h * tiles_w);
+      const int nrem = nxt - nn * tiles_h * tiles_w;
+      const void* xseg = stem_seg(a, nn);
+      if (fast) raw = stem_issue4(xseg, nn, a.H, a.W, 2 * (nrem / tiles_w) * TH - 3, 2 * (nrem % tiles_w) * TW - 3);
+      else stem_issue<INF32>(pv, role, xseg, nn, a.H, a.W, 2 * (nrem / tiles_w) * TH - 3, 2 * (nrem % tiles_w) * TW - 3);
     }
 
     f32x4_t acc[4][2];
@@ -344,7 +354,11 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
   auto issue = [&](int tile) {
     const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
     const int ho0 = (rem / tiles_w) * TH, wo0 = (rem % tiles_w) * TW;
-    if (fast) raw = stem_issue4(a.x, n, a.H, a.W, 2 * ho0 - 3, 2 * wo0 - 3);
+    if (fast) {
+      int ns = n;
+      const void* xseg = stem_seg(a, ns);
+      raw = stem_issue4(xseg, ns, a.H, a.W, 2 * ho0 - 3, 2 * wo0 - 3);
+    }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
       const int p = row + (256 / CPR) * i;
@@ -361,8 +375,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
     if (fast) {
       stem_commit4<T>(hl, raw);
     } else {
-      const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
-      stem_load_halo<T, INF32>(hl, a.x, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
+      int n = tile / (tiles_h * tiles_w);
+      const int rem = tile - n * tiles_h * tiles_w;
+      const void* xseg = stem_seg(a, n);
+      stem_load_halo<T, INF32>(hl, xseg, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
     }
 #pragma unroll
     for (int i = 0; i < YL; ++i) st16(yt + (row + (256 / CPR) * i) * RB + chunk * 16, yreg[i]);

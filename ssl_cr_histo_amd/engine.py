@@ -21,7 +21,7 @@ SslCrDesc = type("SslCrDesc", (C.Structure,), {"_fields_": [
     ("kind", C.c_int), ("x_student", C.c_void_p), ("x_teacher", C.c_void_p), ("in_f32", C.c_int), ("nx", C.c_int),
     ("nu", C.c_int), ("H", C.c_int), ("W", C.c_int), ("target_f", C.c_void_p), ("target_i", C.c_void_p),
     ("lambda_u", C.c_float), ("nx_global", C.c_int), ("nu_global", C.c_int), ("feats", C.c_void_p), ("logits", C.c_void_p),
-    ("logits_t", C.c_void_p), ("losses", C.c_void_p), ("backward", C.c_int)]})
+    ("logits_t", C.c_void_p), ("losses", C.c_void_p), ("backward", C.c_int), ("x_student2", C.c_void_p)]})
 SupDesc = type("SupDesc", (C.Structure,), {"_fields_": [
     ("kind", C.c_int), ("x1", C.c_void_p), ("x2", C.c_void_p), ("x3", C.c_void_p), ("in_f32", C.c_int), ("n", C.c_int),
     ("H", C.c_int), ("W", C.c_int), ("target_f", C.c_void_p), ("target_i", C.c_void_p), ("n_global", C.c_int),
@@ -326,9 +326,11 @@ class Engine:
         x, u_w, u_s = self.as_input(x), self.as_input(u_w), self.as_input(u_s)
         if x.dtype != u_s.dtype or x.dtype != u_w.dtype:
             x, u_w, u_s = x.float(), u_w.float(), u_s.float()
-        xs = torch.cat((x, u_s))                                    # :82
+        # torch.cat((inputs_x, inputs_u_s)) of :82 is not materialised: the stem kernel reads the two segments in place
         nx, nu = x.shape[0], u_w.shape[0]
-        _, _, H, W = xs.shape
+        if u_s.shape[0] != nu or x.shape[1:] != u_s.shape[1:]:
+            raise ValueError("step_ssl_cr: u_w / u_s batch sizes or image shapes differ")
+        _, _, H, W = x.shape
         dev = self.device
         feats = torch.empty((nx + nu, 768), dtype=torch.float32, device=dev)
         logits = torch.empty((nx + nu, student.ncls), dtype=torch.float32, device=dev)
@@ -338,13 +340,13 @@ class Engine:
         y = y.to(dev).contiguous()
         tf = y.float() if k == 0 else None
         ti = y.long() if k == 1 else None
-        d = SslCrDesc(k, xs.data_ptr(), u_w.data_ptr(), int(xs.dtype == torch.float32), nx, nu, H, W,
+        d = SslCrDesc(k, x.data_ptr(), u_w.data_ptr(), int(x.dtype == torch.float32), nx, nu, H, W,
                       None if tf is None else tf.data_ptr(), None if ti is None else ti.data_ptr(), float(lambda_u),
                       int(nx_global or nx * self.world), int(nu_global or nu * self.world), feats.data_ptr(),
-                      logits.data_ptr(), logits_t.data_ptr(), losses.data_ptr(), int(backward))
+                      logits.data_ptr(), logits_t.data_ptr(), losses.data_ptr(), int(backward), u_s.data_ptr())
         L.check(L.lib().sslcr_step_ssl_cr(teacher.handle, student.handle, C.byref(d), L.stream_ptr()))
         self._reduce_losses(losses)
-        student._live_inputs = (xs, u_w, tf, ti)
+        student._live_inputs = (x, u_s, u_w, tf, ti)
         student._note_buffers_changed()
         return dict(losses=losses, feats=feats, logits=logits, logits_t=logits_t)
 

@@ -103,15 +103,20 @@ def pack_stem(w_kcrs, dtype, *, bn=None, eps=1e-5):
     return wf, bias
 
 
-def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False):
-    """x NCHW uint8|fp32 [N,3,H,W] -> NHWC [N,OH,OW,64] in w_packed's dtype (+ partial stats)."""
-    _chk(x_nchw, w_packed, bias)
+def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False, x2=None):
+    """x NCHW uint8|fp32 [N,3,H,W] (optionally followed by a second segment x2, read in place of a torch.cat)
+    -> NHWC [N(+N2),OH,OW,64] in w_packed's dtype (+ partial stats)."""
+    _chk(x_nchw, w_packed, bias, x2)
     N, _, H, W = x_nchw.shape
+    n_split = 0
+    if x2 is not None:
+        assert x2.dtype == x_nchw.dtype and x2.shape[1:] == x_nchw.shape[1:]
+        n_split, N = N, N + x2.shape[0]
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     assert x_nchw.dtype in (torch.uint8, torch.float32)
     y = torch.empty((N, OH, OW, 64), dtype=w_packed.dtype, device=x_nchw.device)
     d = L.StemDesc(L.ptr(x_nchw), L.ptr(w_packed), L.ptr(y), L.ptr(bias), None, N, H, W, OH, OW,
-                   int(x_nchw.dtype == torch.float32), int(relu))
+                   int(x_nchw.dtype == torch.float32), int(relu), L.ptr(x2), int(n_split))
     stats = None
     if want_stats:
         rows = L.lib().sslcr_stem_partial_rows(d)
@@ -121,11 +126,16 @@ def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False):
     return (y, stats) if want_stats else y
 
 
-def stem_wgrad(x_nchw, dy, dw):
-    _chk(x_nchw, dy, dw)
+def stem_wgrad(x_nchw, dy, dw, *, x2=None):
+    _chk(x_nchw, dy, dw, x2)
     N, _, H, W = x_nchw.shape
+    n_split = 0
+    if x2 is not None:
+        assert x2.dtype == x_nchw.dtype and x2.shape[1:] == x_nchw.shape[1:]
+        n_split, N = N, N + x2.shape[0]
     _, OH, OW, _ = dy.shape
-    d = L.StemWgradDesc(L.ptr(x_nchw), L.ptr(dy), L.ptr(dw), N, H, W, OH, OW, int(x_nchw.dtype == torch.float32))
+    d = L.StemWgradDesc(L.ptr(x_nchw), L.ptr(dy), L.ptr(dw), N, H, W, OH, OW, int(x_nchw.dtype == torch.float32),
+                        L.ptr(x2), int(n_split))
     L.check(L.lib().sslcr_stem_wgrad(_dt(dy), d, L.stream_ptr()))
 
 

@@ -228,6 +228,30 @@ def test_stem(shape, in_u8, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("in_u8", [True, False])
+@pytest.mark.parametrize("shape,split", [((5, 64, 64), 2), ((3, 30, 34), 1), ((4, 32, 32), 4)])
+def test_stem_two_segment_input(shape, split, in_u8, dtype):
+    """torch.cat((inputs_x, inputs_u_s)) (eval_BreastPathQ_SSL_CR.py:82) as an address select in the stem kernels:
+    forward and statistics on (x[:split], x2) must be BIT-identical to the same kernel on the concatenated batch,
+    wgrad equal up to the order of its fp32 atomics."""
+    K = _k()
+    N, H, W = shape
+    xu = torch.from_numpy(np.random.RandomState(41).randint(0, 256, (N, 3, H, W), dtype=np.uint8))
+    xin = (xu if in_u8 else xu.float()).to(DEV)
+    a, b = xin[:split].contiguous(), xin[split:].contiguous()
+    wp, _ = K.pack_stem(rnd(42, (64, 3, 7, 7), 0.03).to(DEV), dtype)
+    y0, s0 = K.stem_conv(xin, wp, want_stats=True)
+    y1, s1 = K.stem_conv(a, wp, want_stats=True, x2=b)
+    assert torch.equal(y0, y1) and torch.equal(s0, s1)
+    dy = to_dev(q(rnd(43, tuple(y0.shape)), dtype), dtype)
+    dw0 = torch.zeros((64, 3, 7, 7), dtype=torch.float32, device=DEV)
+    dw1 = torch.zeros_like(dw0)
+    K.stem_wgrad(xin, dy, dw0)
+    K.stem_wgrad(a, dy, dw1, x2=b)
+    close(dw1, dw0.cpu(), 1e-5, "stem wgrad two-segment")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("hw", [(16, 16), (15, 13)])          # odd sizes: ragged 2x2 blocks / pooling windows at the border
 def test_bn_forward_chain(hw, dtype):
     """conv stats -> finalize (x3 replay) -> bn_act / pool, against F.batch_norm train mode."""
