@@ -247,7 +247,7 @@ def main():
             # HBM traffic of this kernel comes from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), which
             # cannot run inside this process: report the committed measurement of one instance beside its algorithmic bytes
             pmc = os.path.join(ROOT, "profiles", "r01_e_pmc_layer1_traffic.json")
-            if os.path.exists(pmc) and "conv3x3_h16_kernel<unsigned short, 64, 2, false>" in d["name"]:
+            if os.path.exists(pmc) and "conv3x3_h16_kernel<unsigned short, 64, 2, false" in d["name"]:
                 # measured on the N=640 layer1 instance: FETCH_SIZE 164 215 KiB (x2) + WRITE_SIZE 327 680 KiB = 671.8 MB for
                 # 671.2 MB algorithmic; the step's launches of this kernel differ only in N, so the ratio carries over
                 ratio = 671.8 / 671.2

@@ -56,7 +56,12 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define SSLCR_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0f70) /* vmcnt(0), lgkmcnt/expcnt untouched */
 
 // XF: the producer's BatchNorm(+ReLU) is applied to the input on its way into LDS (a.in_scale != nullptr)
-template <typename T, int BKO, int WK, bool XF>
+// WR: the whole filter bank stays resident in LDS (C == one slab and K == BKO, i.e. the 64->64 layer1 convs: 9 x 64 x 128 B
+//     = 72 KB next to the 54 KB halo).  A stage then has no weight DMA, no publish/free barriers and no vmcnt wait before its
+//     15th step, so the next halo (and the residual) is requested at the TOP of the stage and has ~14 steps to land; with
+//     the ring, the short 8-MFMA steps of this shape left the HBM round trip of the halo half exposed and paid 8 barriers
+//     per 144 MFMAs.
+template <typename T, int BKO, int WK, bool XF, bool WR>
 __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items) {
   constexpr int NT = 256 * WK;
   constexpr int EPC = Elem<T>::EPC;
@@ -70,8 +75,9 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   static_assert(NLD <= 16 && WLD >= 1, "staging shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_halo = smem;
-  char* s_w = smem + HBUF;                    // [2][TPB][BKO][128 B]
-  float* s_scale = reinterpret_cast<float*>(smem + HBUF + 2 * TPB * WBUF);
+  constexpr int NRING = WR ? 3 : 2;           // tap groups held in LDS
+  char* s_w = smem + HBUF;                    // [NRING][TPB][BKO][128 B]
+  float* s_scale = reinterpret_cast<float*>(smem + HBUF + NRING * TPB * WBUF);
   float* s_shift = s_scale + a.C;
   // BatchNorm (sum, sumsq) of this workgroup's current kout block, per 64-pixel wave row: [4][2][BKO].  Items add into
   // it with ds_add_f32 (each entry has exactly one writer wave, so the order -- and the fp32 result -- is deterministic);
@@ -227,6 +233,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   // ---- pipeline fill: halo of (first item, slab 0) and ring half 0 <- taps 0..2
   Geo cur = geom(first);
   dma_w(cur.k0, 0, 0, 0);
+  if constexpr (WR) { dma_w(cur.k0, 0, 3, 1); dma_w(cur.k0, 0, 6, 2); }
   load_halo(cur, 0);
   if (XF) __syncthreads();
   load_affine(0);
@@ -239,6 +246,16 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
 
   char* yg = reinterpret_cast<char*>(a.y);
   const char* rg = reinterpret_cast<const char*>(a.residual);
+  // bf16 residual (teacher conv2 / the skip gradient of a block's first dgrad): requested with the next halo in the middle
+  // of the item's LAST stage, so its HBM round trip sits under six steps of MFMAs instead of in front of the epilogue
+  // (the epilogue-time load cost 57-80 us per layer1 launch, one exposed latency per tile)
+  constexpr bool RPRE = sizeof(T) == 2 && !XF;
+  constexpr int RQ = 4 * TK / EPC;
+  u32x4_t rres[RPRE ? TP : 1][RPRE ? RQ : 1];
+  auto out_off = [&](const Geo& q, int p) {
+    const int h = q.h0 + wp * 4 + p, w = q.w0 + li;
+    return ((((size_t)q.n0 * a.H + h) * a.W + w) * a.K + q.k0 + wk * (BKO / WK) + g * (4 * TK)) * sizeof(T);
+  };
   int wb = 0, item = first, slab = 0;
   for (;;) {
     // the stage after this one: next slab of this tile, or slab 0 of the next item (the last stage of the walk re-requests
@@ -257,14 +274,29 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
     //   group end   : barrier F            -> everybody is done with this group's half; it may be overwritten
     //   mid G1      : request the next stage's halo (HBM), mid G2 it has landed (same vmcnt(0)); steps 15-17 transform it
     //   stage end   : barrier, six ds_write_b128, barrier -- the only place the fragment pipeline drains
-    dma_w(cur.k0, slab, 3, wb ^ 1);
+    auto load_res = [&]() {
+      if constexpr (RPRE) {
+        if (rg && last) {
+#pragma unroll
+          for (int p = 0; p < TP; ++p)
+#pragma unroll
+            for (int q = 0; q < RQ; ++q) rres[p][q] = ld16(rg + out_off(cur, p) + q * 16);
+        }
+      }
+    };
+    if constexpr (WR) {
+      load_res();
+      load_halo(nxt, 0);
+    } else {
+      dma_w(cur.k0, slab, 3, wb ^ 1);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
       // the scheduler fences keep "request the next fragments, then run this step's MFMAs (with the halo transform under
       // them)" in that order; left alone the compiler serialises read -> wait -> MFMA, sinks prefetches down to their
       // first use and moves the VALU work into the barrier-to-barrier section of the stage boundary
-      if (i < 17) frags((i + 1) & 1, i + 1, (((i + 1) / 6) & 1) ? ring1 : ring0);
+      if (i < 17) frags((i + 1) & 1, i + 1, WR ? s_w + ((i + 1) / 6) * (TPB * WBUF) : ((((i + 1) / 6) & 1) ? ring1 : ring0));
       if (sizeof(T) != 2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < TK; ++t)
@@ -284,16 +316,21 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
         for (int j = (i - 15); j < NLD; j += 3) xform_one(j);
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (i % 6 == 2) {
+      if (WR && i == 14) {
+        SSLCR_WAIT_VM0();                                 // halo + residual (and the previous epilogue's stores) have landed
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!WR && i % 6 == 2) {
         SSLCR_WAIT_VM0();
         __syncthreads();                                  // P
         if (i == 8) {
+          load_res();
           load_halo(nxt, nslab);
           load_affine(nslab);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (i == 5 || i == 11) {
+      if (!WR && (i == 5 || i == 11)) {
         __syncthreads();                                  // F
         if (i == 5) dma_w(cur.k0, slab, 6, wb); else dma_w(nxt.k0, nslab, 0, wb ^ 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -303,7 +340,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
     store_halo();
     __syncthreads();
     wb ^= 1;
-    frags(0, 0, s_w + wb * (TPB * WBUF));      // first fragments of the next stage: in flight under the epilogue
+    frags(0, 0, WR ? s_w : s_w + wb * (TPB * WBUF));      // first fragments of the next stage: in flight under the epilogue
     __builtin_amdgcn_sched_barrier(0);
 
     if (last) {
@@ -314,8 +351,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
       for (int j = 0; j < 4 * TK; ++j) bias[j] = a.bias ? a.bias[kb + j] : 0.f;
 #pragma unroll
       for (int p = 0; p < TP; ++p) {
-        const int h = cur.h0 + wp * 4 + p, w = cur.w0 + li;
-        const size_t off = ((((size_t)cur.n0 * a.H + h) * a.W + w) * a.K + kb) * sizeof(T);
+        const size_t off = out_off(cur, p);
         float v[4 * TK];
 #pragma unroll
         for (int t = 0; t < TK; ++t)
@@ -326,7 +362,8 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
           float* vq = v + q * EPC;
           if (rg) {
             float rr[EPC];
-            Elem<T>::unpack(ld16(rg + off + q * 16), rr);
+            if constexpr (RPRE) Elem<T>::unpack(rres[p][q], rr);
+            else Elem<T>::unpack(ld16(rg + off + q * 16), rr);
 #pragma unroll
             for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
           }
@@ -409,11 +446,14 @@ int conv_h16_rows(const ConvArgs& a) {
   return (n_items < device_cus() ? n_items : device_cus()) * 4;
 }
 
-template <typename T, int BKO, int WK, bool XF>
+// bf16 64 -> 64: one 128-byte slab of input channels and one kout block, the filter bank fits LDS whole
+static bool h16_resident(const ConvArgs& a) { return a.C == 64 && a.K == 64; }
+
+template <typename T, int BKO, int WK, bool XF, bool WR = false>
 static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
-  const size_t lds = 18 * 24 * 128 + 2 * 3 * BKO * 128 + 2 * a.C * sizeof(float) + 8 * BKO * sizeof(float);
+  const size_t lds = 18 * 24 * 128 + (WR ? 3 : 2) * 3 * BKO * 128 + 2 * a.C * sizeof(float) + 8 * BKO * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  auto kern = conv3x3_h16_kernel<T, BKO, WK, XF>;
+  auto kern = conv3x3_h16_kernel<T, BKO, WK, XF, WR>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -431,6 +471,8 @@ template <typename T>
 static hipError_t launch_ht(const ConvArgs& a, hipStream_t st) {
   const bool xf = a.in_scale != nullptr;
   if (a.K % 128 == 0) return xf ? launch_h<T, 128, 2, true>(a, st) : launch_h<T, 128, 2, false>(a, st);
+  if constexpr (sizeof(T) == 2)
+    if (h16_resident(a)) return xf ? launch_h<T, 64, 2, true, true>(a, st) : launch_h<T, 64, 2, false, true>(a, st);
   return xf ? launch_h<T, 64, 2, true>(a, st) : launch_h<T, 64, 2, false>(a, st);
 }
 
@@ -441,11 +483,13 @@ hipError_t launch_conv_h16(int dtype, const ConvArgs& a, hipStream_t st) {
 const char* conv_h16_name(int dtype, const ConvArgs& a) {
   const bool bf = dtype == DT_BF16, xf = a.in_scale != nullptr;
   if (a.K % 128 == 0) {
-    if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, true>" : "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, false>";
-    return xf ? "sslcr::conv3x3_h16_kernel<float, 128, 2, true>" : "sslcr::conv3x3_h16_kernel<float, 128, 2, false>";
+    if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, true, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, false, false>";
+    return xf ? "sslcr::conv3x3_h16_kernel<float, 128, 2, true, false>" : "sslcr::conv3x3_h16_kernel<float, 128, 2, false, false>";
   }
-  if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false>";
-  return xf ? "sslcr::conv3x3_h16_kernel<float, 64, 2, true>" : "sslcr::conv3x3_h16_kernel<float, 64, 2, false>";
+  if (bf && h16_resident(a))
+    return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true, true>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false, true>";
+  if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false, false>";
+  return xf ? "sslcr::conv3x3_h16_kernel<float, 64, 2, true, false>" : "sslcr::conv3x3_h16_kernel<float, 64, 2, false, false>";
 }
 
 }  // namespace sslcr

@@ -96,6 +96,8 @@ def test_conv_fwd_raw_stats(case, dtype):
               (4, 8, 8, 512, 512, 3, 1, 1): "conv3x3_halo256_kernel"}.get(case)
     if expect:
         assert expect in K.last_conv_kernel, K.last_conv_kernel
+    if case == (70, 32, 32, 64, 64, 3, 1, 1) and dtype == 1:      # 280 tiles on 256 workgroups: the resident-filter walk
+        assert "conv3x3_h16_kernel<unsigned short, 64, 2, false, true>" in K.last_conv_kernel, K.last_conv_kernel
     want = R.conv_fwd(x, w, stride, pad)
     close(y, want, TOL[dtype], "conv raw")
     s, ss = R.channel_stats(want)
