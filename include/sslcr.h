@@ -136,6 +136,9 @@ typedef struct sslcr_bn_bwd_desc {
   const void* pool_y;     /* optional with pool_dy: the max-pool OUTPUT saved by the forward, [N][pOH][pOW][C].  With it the reduce
                              pass reads only the pooled tensors: a pooled gradient lands on exactly one input pixel, whose
                              relu(bn(x)) IS the pooled output, so (x - mean) = (y - shift) / scale - mean where y > 0 */
+  int g_in_reduce;        /* with yact and gout: the REDUCE pass writes the masked gradient g = dy * (yact > 0) to gout, and the
+                             apply pass reads it back instead of dy and yact (one tensor read less; the identity path of a
+                             residual block needs g anyway).  Not with pool_dy. */
 } sslcr_bn_bwd_desc;
 int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream);

@@ -401,6 +401,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
     for (size_t p = (size_t)blockIdx.x * rpp + rl; p < a.pixels; p += (size_t)gridDim.x * rpp) {
       float g[EPC], xf[EPC];
       bn_bwd_g<T>(a, p * cols + col, rsc, rsh, g, xf);
+      if (a.g_in_reduce) st16(reinterpret_cast<char*>(a.gout) + (p * cols + col) * 16, Elem<T>::pack(g));
 #pragma unroll
       for (int e = 0; e < EPC; ++e) { s0[e] += g[e]; s1[e] = fmaf(g[e], xf[e] - mean[e], s1[e]); }
     }
@@ -622,7 +623,11 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st) {
+hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a0, hipStream_t st) {
+  BnBwdArgs a = a0;
+  if (a.g_in_reduce) {      // the reduce pass left the masked gradient in gout: plain dy from here on
+    a.dy = a.gout; a.yact = nullptr; a.relu_from_x = 0; a.gout = nullptr; a.g_in_reduce = 0;
+  }
   if (a.pool_dy) {
     const int epc = dtype == DT_BF16 ? 8 : 4;
     const size_t items = (a.pixels / ((size_t)a.pH * a.pW)) * ((a.pH + 1) / 2) * ((a.pW + 1) / 2) * (a.C / epc);

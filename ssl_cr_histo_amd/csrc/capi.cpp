@@ -108,11 +108,13 @@ int sslcr_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C
 int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream) {
   DT_OK(dtype);
   NEED(d && (d->dy || (d->pool_dy && d->pool_argmax)) && d->x && d->sums && d->mean, "null");
+  NEED(!d->g_in_reduce || (d->yact && d->gout && d->dy && !d->pool_dy), "g_in_reduce needs dy, yact and gout");
   return check(launch_bn_bwd_reduce(dtype, *d, (hipStream_t)stream), "bn_bwd_reduce");
 }
 int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream) {
   DT_OK(dtype);
   NEED(d && (d->dy || (d->pool_dy && d->pool_argmax)) && d->x && d->sums && d->dx && d->mean && d->invstd && d->scale, "null");
+  NEED(!d->g_in_reduce || (d->yact && d->gout && d->dy && !d->pool_dy), "g_in_reduce needs dy, yact and gout");
   return check(launch_bn_bwd_apply(dtype, *d, (hipStream_t)stream), "bn_bwd_apply");
 }
 int sslcr_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, void* stream) {

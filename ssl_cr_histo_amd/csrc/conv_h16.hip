@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   if (XF)
     for (int c = tid; c < a.C; c += NT) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
   for (int i = tid; i < 8 * BKO; i += NT) s_stat[i] = 0.f;
+  // the (folded-BatchNorm) bias of all K outputs: read from LDS in the epilogue.  As global loads -- even skipped ones, when
+  // there is no bias -- they put a compiler vmcnt(0) in front of the output stores
+  float* s_bias = s_stat + 8 * BKO;
+  for (int i = tid; i < a.K; i += NT) s_bias[i] = a.bias ? a.bias[i] : 0.f;
   const float relu_lo = a.in_relu ? 0.f : -__builtin_inff();
 
   // XCD-aware walk: blocks land on XCD (blockIdx % 8); each XCD takes a contiguous run of tiles per round so that
@@ -245,7 +249,9 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   frags(0, 0, s_w);
 
   char* yg = reinterpret_cast<char*>(a.y);
-  const char* rg = reinterpret_cast<const char*>(a.residual);
+  // no residual with an input transform (conv_h16_ok): a residual load in the epilogue -- even one skipped at run time --
+  // made the compiler put a vmcnt(0) in front of every output store, i.e. eight serial write round trips per item
+  const char* rg = XF ? nullptr : reinterpret_cast<const char*>(a.residual);
   // bf16 residual (teacher conv2 / the skip gradient of a block's first dgrad): requested with the next halo in the middle
   // of the item's LAST stage, so its HBM round trip sits under six steps of MFMAs instead of in front of the epilogue
   // (the epilogue-time load cost 57-80 us per layer1 launch, one exposed latency per tile)
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
       const int kb = cur.k0 + wk * (BKO / WK) + g * (4 * TK);
       float bias[4 * TK];
 #pragma unroll
-      for (int j = 0; j < 4 * TK; ++j) bias[j] = a.bias ? a.bias[kb + j] : 0.f;
+      for (int j = 0; j < 4 * TK; ++j) bias[j] = s_bias[kb + j];
 #pragma unroll
       for (int p = 0; p < TP; ++p) {
         const size_t off = out_off(cur, p);
@@ -437,6 +443,7 @@ static int device_cus() {
 }
 
 bool conv_h16_ok(int dtype, const ConvArgs& a) {
+  if (a.in_scale && a.residual) return false;          // not a ResNet combination; the older halo kernels take it
   return conv_halo256_mode(dtype, a) == 16 && conv_halo256_mode(DT_BF16, a) == 16;
 }
 // partial-statistics rows the launch will write: four per workgroup (see s_stat)
@@ -451,7 +458,7 @@ static bool h16_resident(const ConvArgs& a) { return a.C == 64 && a.K == 64; }
 
 template <typename T, int BKO, int WK, bool XF, bool WR = false>
 static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
-  const size_t lds = 18 * 24 * 128 + (WR ? 3 : 2) * 3 * BKO * 128 + 2 * a.C * sizeof(float) + 8 * BKO * sizeof(float);
+  const size_t lds = 18 * 24 * 128 + (WR ? 3 : 2) * 3 * BKO * 128 + 2 * a.C * sizeof(float) + 8 * BKO * sizeof(float) + a.K * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   auto kern = conv3x3_h16_kernel<T, BKO, WK, XF, WR>;
   static bool attr_done = false;

@@ -615,12 +615,13 @@ struct PoolSrc {            // gradient arriving through the stem max-pool (see 
 };
 
 int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
-                void* dx, void* gout, size_t pixels, double count, hipStream_t st, const PoolSrc* pool = nullptr) {
+                void* dx, void* gout, size_t pixels, double count, hipStream_t st, const PoolSrc* pool = nullptr, int g_in_reduce = 0) {
   sslcr_ctx* c = n->ctx;
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.x = x; a.yact = yact; a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
   a.sums = c->bn_sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
+  a.g_in_reduce = (g_in_reduce && yact && gout) ? 1 : 0;
   if (pool) { a.pool_dy = pool->dy; a.pool_argmax = pool->argmax; a.pH = pool->H; a.pW = pool->W; a.pOH = pool->OH; a.pOW = pool->OW; a.pool_y = pool->y; }
   const bool synced = c->comm && c->bn_sync;
   a.count = synced ? count * c->world : count;
@@ -635,8 +636,8 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
     r.flops = 0.0;
     // algorithmic bytes: read dy (or the 4x smaller pooled gradient + 1-byte argmax), x, (saved output for the ReLU mask); write dx (, g)
     const double t = (double)pixels * bn.C * c->esz();
-    const double rd = (pool ? 0.25 * t + 0.25 * (double)pixels * bn.C : t) + t + (yact ? t : 0.0);
-    r.bytes = rd + t + (gout ? t : 0.0);
+    const double rd = (pool ? 0.25 * t + 0.25 * (double)pixels * bn.C : t) + t + ((yact && !a.g_in_reduce) ? t : 0.0);
+    r.bytes = rd + t + ((gout && !a.g_in_reduce) ? t : 0.0);
     (void)hipEventRecord(r.e0, st);
     hipError_t e = launch_bn_bwd_apply(c->dtype, a, st);
     (void)hipEventRecord(r.e1, st);
@@ -713,11 +714,11 @@ int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pa
     const char* X = i == 0 ? ps.pooled : ps.blk[i - 1].y;
     const size_t opix = (size_t)N * oh * ow;
     const bool need_dx = low < B.pstart;          // something upstream of this block is trainable
-    // bn2 (+ relu mask from the block output) ; G = masked gradient feeds the identity path
-    TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, (!B.has_ds && need_dx) ? G : nullptr, opix,
-                     (double)opix, st));
+    // bn2 (+ relu mask from the block output): its REDUCE pass leaves G = dOut * (y > 0) in scratch; the apply pass, the
+    // projection shortcut's BatchNorm and the identity path all read G instead of (dOut, y) again
+    TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, nullptr, 1));
     if (B.has_ds)
-      TRYI(bn_backward(n, B.bd, ps.bn[B.bd.bidx], dOut, ps.blk[i].rawd, ps.blk[i].y, 0, dRawD, nullptr, opix, (double)opix, st));
+      TRYI(bn_backward(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st));
     TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
     {
       ConvArgs a = conv_args(B.c2, dRaw2, B.c2.w_dg, dAct1, N, oh, ow);      // dgrad 3x3/1: gather over dRaw2 [.,K] with [C][R][S][K]

@@ -201,8 +201,9 @@ def avgpool_bwd(dy, shape, dtype):
     return dx
 
 
-def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, want_g=False, count=None, pool=None):
-    """-> (dx, sums[2,C] fp64, g|None)."""
+def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, want_g=False, count=None, pool=None,
+           g_in_reduce=False):
+    """-> (dx, sums[2,C] fp64, g|None).  g_in_reduce: the reduce pass writes g and the apply pass reads it (needs yact, want_g)."""
     _chk(x, scale, shift, mean, invstd, yact)
     if dy is not None:
         _chk(dy)
@@ -213,7 +214,7 @@ def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, w
     g = torch.empty_like(x) if want_g else None
     d = L.BnBwdDesc(L.ptr(dy), L.ptr(x), L.ptr(yact), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(sums),
                     L.ptr(dx), L.ptr(g), pixels, Cn, int(relu_from_x), float(count if count is not None else pixels),
-                    None, None, 0, 0, 0, 0, None)
+                    None, None, 0, 0, 0, 0, None, int(g_in_reduce))
     if pool is not None:          # pool = (pooled_dy [N,OH,OW,C], argmax u8[, pooled output y]): dy arrives through the stem max-pool
         pdy, pam = pool[0], pool[1]
         _chk(pdy, pam)

@@ -356,6 +356,12 @@ def test_bn_backward(mode, dtype):
     close(db, br.grad, t, "dbeta")
     mask = (out.detach() > 0).float() if mode != "none" else torch.ones_like(out)
     close(g, dy * R.nhwc(mask), 1e-6, "g")
+    if mode == "yact":
+        # the engine's form for a block's second BatchNorm: the reduce pass writes g, the apply pass reads it back -- same bits
+        dx2, sums2, g2 = K.bn_bwd(to_dev(dy, dtype), to_dev(x, dtype), scale.to(DEV), shift.to(DEV), mean.float().to(DEV),
+                                  invstd.float().to(DEV), yact=yact, want_g=True, g_in_reduce=True)
+        assert torch.equal(g2, g) and torch.equal(dx2, dx)
+        close(sums2, sums, 1e-12, "sums with g written by the reduce pass")
 
 
 def test_linear_and_loss():
