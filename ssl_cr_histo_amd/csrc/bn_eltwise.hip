@@ -198,8 +198,77 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs 
   }
 }
 
+// Row form (256 % (C / EPC) == 0, every ResNet width): a workgroup walks output rows (n, oh); a thread keeps its channel
+// chunk, so the index arithmetic is one uniform division per ROW instead of six 64-bit divisions per 16-byte chunk, and the
+// nine window loads are unconditional (clamped address, validity by select) so they are all in flight together.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(const PoolFwdArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = a.C / EPC;
+  const int ppp = 256 / cols;                 // output pixels per pass
+  const int col = threadIdx.x % cols, pw0 = threadIdx.x / cols;
+  const char* x = reinterpret_cast<const char*>(a.x) + (size_t)col * 16;
+  float psc[EPC], psh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { psc[e] = a.scale[col * EPC + e]; psh[e] = a.shift[col * EPC + e]; }
+  const int rows = a.N * a.OH;
+  const size_t rowb = (size_t)a.W * a.C * sizeof(T);
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / a.OH, oh = r - n * a.OH;
+    const int h0 = 2 * oh - 1;
+    const char* xn = x + (size_t)n * a.H * rowb;
+    for (int ow = pw0; ow < a.OW; ow += ppp) {
+      const int w0 = 2 * ow - 1;
+      u32x4_t v[9];
+#pragma unroll
+      for (int wi = 0; wi < 9; ++wi) {
+        int h = h0 + wi / 3, w = w0 + wi % 3;
+        h = h < 0 ? 0 : (h >= a.H ? a.H - 1 : h);
+        w = w < 0 ? 0 : (w >= a.W ? a.W - 1 : w);
+        v[wi] = ld16(xn + (size_t)h * rowb + (size_t)w * a.C * sizeof(T));
+      }
+      float best[EPC];
+      int arg[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { best[e] = -INFINITY; arg[e] = 0; }
+#pragma unroll
+      for (int wi = 0; wi < 9; ++wi) {
+        const int h = h0 + wi / 3, w = w0 + wi % 3;
+        const bool ok = h >= 0 && w >= 0 && h < a.H && w < a.W;
+        float f[EPC];
+        Elem<T>::unpack(v[wi], f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          const float q = fmaxf(fmaf(f[e], psc[e], psh[e]), 0.f);
+          if (ok && q > best[e]) { best[e] = q; arg[e] = wi; }
+        }
+      }
+      const size_t i = ((size_t)r * a.OW + ow) * cols + col;
+      st16_nt(reinterpret_cast<char*>(a.y) + i * 16, Elem<T>::pack(best));
+      if (a.argmax) {
+        uint8_t* ap = a.argmax + i * EPC;
+        if (EPC == 8) {
+          uint32_t lo = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+          uint32_t hi = arg[4 % EPC] | (arg[5 % EPC] << 8) | (arg[6 % EPC] << 16) | (arg[7 % EPC] << 24);
+          *reinterpret_cast<u32x2_t*>(ap) = u32x2_t{lo, hi};
+        } else {
+          *reinterpret_cast<uint32_t*>(ap) = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+        }
+      }
+    }
+  }
+}
+
 hipError_t launch_bn_relu_maxpool(int dtype, const PoolFwdArgs& a, hipStream_t st) {
   size_t px = (size_t)a.N * a.OH * a.OW;
+  const int cols = a.C / (dtype == DT_BF16 ? 8 : 4);
+  if (cols >= 1 && cols <= 256 && 256 % cols == 0) {
+    const int rows = a.N * a.OH;
+    const int grid = rows < 256 * 16 ? rows : 256 * 16;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(bn_relu_maxpool_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(bn_relu_maxpool_rows_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   if (dtype == DT_BF16) {
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16_t>, dim3(ew_grid(px * (a.C / 8))), dim3(256), 0, st, a);
   } else {

@@ -327,6 +327,27 @@ def test_bn_forward_chain(hw, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("C", [64, 24, 512])      # 24: a width whose chunk count does not divide 256 (generic kernel, not the row form)
+@pytest.mark.parametrize("hw", [(16, 16), (9, 7), (2, 2)])
+def test_bn_relu_maxpool_shapes(hw, C, dtype):
+    """maxpool3x3/2 pad 1 of relu(scale*x+shift) with argmax codes: values against torch, codes through the backward."""
+    K = _k()
+    N, (H, W) = 3, hw
+    x = q(rnd(61, (N, H, W, C), 2.0), dtype)
+    sc, sh = rnd(62, (C,)), rnd(63, (C,))
+    sc[1] = 0.0                                      # a gamma == 0 channel: every window element ties, the first one wins
+    pooled, am = K.bn_relu_maxpool(to_dev(x, dtype), sc.to(DEV), sh.to(DEV))
+    act = F.relu(R.nchw(x) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+    ref = F.max_pool2d(act, 3, 2, 1)
+    close(pooled, R.nhwc(ref), 1e-6 if dtype == 0 else 1e-2, "maxpool values")
+    if dtype == 0:
+        dyp = rnd(64, tuple(ref.shape))
+        ref.backward(dyp)
+        dx = K.maxpool_relu_bwd(to_dev(R.nhwc(dyp), dtype), am, to_dev(x, dtype), sc.to(DEV), sh.to(DEV))
+        close(dx, R.nhwc(act.grad * (act > 0)), 1e-6, "maxpool+relu backward through the recorded argmax")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("mode", ["yact", "from_x", "none"])
 def test_bn_backward(mode, dtype):
     K = _k()
