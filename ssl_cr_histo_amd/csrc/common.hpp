@@ -115,4 +115,70 @@ __device__ __forceinline__ int wperm(int r) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- output stage shared by the convolution kernels.  A lane owns the 4*TK consecutive kouts starting at its kb of TP
+// pixels: acc[TK][TP], byte offsets off[p] of (pixel, kb) in y (a valid address also where !ok[p]).
+// The optional operands are COMPILE-TIME here and all their loads are issued before the first store.  Written as run-time
+// `if (residual) load` inside the store loop, the compiler put an s_waitcnt vmcnt(0) in front of every store -- also when
+// the loads were skipped -- and vmcnt retires in order, so each 16-byte store waited out the full write round trip of the
+// one before it (conv_dma: a quarter of the kernel; ISA: store, load, vmcnt(0), store, ...).
+template <typename T, int TK, int TP, bool RES, bool ACC, bool RELU>
+__device__ __forceinline__ void conv_store_tile_t(const f32x4_t (&acc)[TK][TP], const float (&bias)[4 * TK], const size_t (&off)[TP],
+                                                  const bool (&ok)[TP], char* yg, const char* rg) {
+  constexpr int EPC = Elem<T>::EPC, RQ = 4 * TK / EPC;
+  u32x4_t r1[RES ? TP : 1][RES ? RQ : 1], r2[ACC ? TP : 1][ACC ? RQ : 1];
+  if constexpr (RES) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) r1[p][q] = ld16(rg + off[p] + q * 16);
+  }
+  if constexpr (ACC) {
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+      for (int q = 0; q < RQ; ++q) r2[p][q] = ld16(yg + off[p] + q * 16);
+  }
+#pragma unroll
+  for (int p = 0; p < TP; ++p) {
+    float v[4 * TK];
+#pragma unroll
+    for (int t = 0; t < TK; ++t)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[t * 4 + j] = acc[t][p][j] + bias[t * 4 + j];
+#pragma unroll
+    for (int q = 0; q < RQ; ++q) {
+      float* vq = v + q * EPC;
+      if constexpr (RES) {
+        float rr[EPC];
+        Elem<T>::unpack(r1[p][q], rr);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
+      }
+      if constexpr (ACC) {
+        float rr[EPC];
+        Elem<T>::unpack(r2[p][q], rr);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
+      }
+      if constexpr (RELU) {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) vq[e] = fmaxf(vq[e], 0.f);
+      }
+      if (ok[p]) st16(yg + off[p] + q * 16, PackH<T>::run(vq));
+    }
+  }
+}
+template <typename T, int TK, int TP>
+__device__ __forceinline__ void conv_store_tile(const f32x4_t (&acc)[TK][TP], const float (&bias)[4 * TK], const size_t (&off)[TP],
+                                                const bool (&ok)[TP], char* yg, const char* rg, bool accumulate, bool relu) {
+  // uniform three-way dispatch: eight straight-line bodies
+  if (rg) {
+    if (accumulate) { if (relu) conv_store_tile_t<T, TK, TP, true, true, true>(acc, bias, off, ok, yg, rg); else conv_store_tile_t<T, TK, TP, true, true, false>(acc, bias, off, ok, yg, rg); }
+    else { if (relu) conv_store_tile_t<T, TK, TP, true, false, true>(acc, bias, off, ok, yg, rg); else conv_store_tile_t<T, TK, TP, true, false, false>(acc, bias, off, ok, yg, rg); }
+  } else {
+    if (accumulate) { if (relu) conv_store_tile_t<T, TK, TP, false, true, true>(acc, bias, off, ok, yg, rg); else conv_store_tile_t<T, TK, TP, false, true, false>(acc, bias, off, ok, yg, rg); }
+    else { if (relu) conv_store_tile_t<T, TK, TP, false, false, true>(acc, bias, off, ok, yg, rg); else conv_store_tile_t<T, TK, TP, false, false, false>(acc, bias, off, ok, yg, rg); }
+  }
+}
+
 }  // namespace sslcr

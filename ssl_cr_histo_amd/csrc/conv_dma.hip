@@ -185,42 +185,20 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   }
   char* yg = reinterpret_cast<char*>(a.y);
   const char* rg = reinterpret_cast<const char*>(a.residual);
+  size_t off[TP];
+  bool ok[TP];
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
-    const int m = m0 + wp * 64 + p * 16 + li;
-    if (m >= M) continue;
+    const int mm = m0 + wp * 64 + p * 16 + li;
+    ok[p] = mm < M;
+    const int m = ok[p] ? mm : M - 1;          // a valid pixel for the (unconditional) operand loads
     const int n = m / PHW, rem = m - n * PHW;
     int ph = rem / a.PW, pw = rem - ph * a.PW;
     ph = ph * pmul + a.pix_off_h; pw = pw * pmul + a.pix_off_w;
     const size_t opix = ((size_t)n * a.OH + (size_t)ph * a.osh) * a.OW + (size_t)pw * a.osh;
-    const size_t off = (opix * a.K + kb) * sizeof(T);
-    float v[4 * TK];
-#pragma unroll
-    for (int t = 0; t < TK; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[t * 4 + j] = acc[t][p][j] + bias[t * 4 + j];
-#pragma unroll
-    for (int q = 0; q < 4 * TK / EPC; ++q) {
-      float* vq = v + q * EPC;
-      if (rg) {
-        float rr[EPC];
-        Elem<T>::unpack(ld16(rg + off + q * 16), rr);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
-      }
-      if (a.accumulate) {
-        float rr[EPC];
-        Elem<T>::unpack(ld16(yg + off + q * 16), rr);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
-      }
-      if (a.relu) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) vq[e] = fmaxf(vq[e], 0.f);
-      }
-      st16(yg + off + q * 16, PackH<T>::run(vq));
-    }
+    off[p] = (opix * a.K + kb) * sizeof(T);
   }
+  conv_store_tile<T, TK, TP>(acc, bias, off, ok, yg, rg, a.accumulate != 0, a.relu != 0);
 
   if (a.stats) {
     // rows >= M were staged as zeros -> contribute 0.  Sum over this wave's 64 pixels.

@@ -253,38 +253,31 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
   // ---------------- epilogue
   const int kb = k0 + wk * (BKO / WK) + g * (4 * TK);
   float bias[4 * TK];
+  if (a.bias) {
 #pragma unroll
-  for (int j = 0; j < 4 * TK; ++j) bias[j] = a.bias ? a.bias[kb + j] : 0.f;
+    for (int q = 0; q < TK; ++q) {
+      const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(a.bias + kb + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bias[4 * q + j] = b4[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4 * TK; ++j) bias[j] = 0.f;
+  }
   char* yg = reinterpret_cast<char*>(a.y);
   const char* rg = reinterpret_cast<const char*>(a.residual);
+  size_t off[TP];
+  bool ok[TP];
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
     const int pg = wp * 4 + p;
     int n, h, w;
     if (TW == 16) { n = n0; h = h0 + pg; w = w0 + li; }
     else { n = n0 + (pg >> 2); h = h0 + 2 * (pg & 3) + (li >> 3); w = w0 + (li & 7); }
-    const size_t off = ((((size_t)n * a.H + h) * a.W + w) * a.K + kb) * sizeof(T);
-    float v[4 * TK];
-#pragma unroll
-    for (int t = 0; t < TK; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[t * 4 + j] = acc[t][p][j] + bias[t * 4 + j];
-#pragma unroll
-    for (int q = 0; q < 4 * TK / EPC; ++q) {
-      float* vq = v + q * EPC;
-      if (rg) {
-        float rr[EPC];
-        Elem<T>::unpack(ld16(rg + off + q * 16), rr);
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
-      }
-      if (a.relu) {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) vq[e] = fmaxf(vq[e], 0.f);
-      }
-      st16(yg + off + q * 16, Elem<T>::pack(vq));
-    }
+    off[p] = ((((size_t)n * a.H + h) * a.W + w) * a.K + kb) * sizeof(T);
+    ok[p] = true;
   }
+  conv_store_tile<T, TK, TP>(acc, bias, off, ok, yg, rg, false, a.relu != 0);
   if (a.stats) {
     float s1[4 * TK], s2[4 * TK];
 #pragma unroll
