@@ -246,17 +246,18 @@ def main():
                                         "roofs are reported (roofline = MFMA kernel, roofline_hbm = that kernel)")
             # HBM traffic of this kernel comes from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), which
             # cannot run inside this process: report the committed measurement of one instance beside its algorithmic bytes
-            pmc = os.path.join(ROOT, "profiles", "r01_e_pmc_layer1_traffic.json")
-            if os.path.exists(pmc) and "conv3x3_h16_kernel<unsigned short, 64, 2, false" in d["name"]:
-                # measured on the N=640 layer1 instance: FETCH_SIZE 164 215 KiB (x2) + WRITE_SIZE 327 680 KiB = 671.8 MB for
-                # 671.2 MB algorithmic; the step's launches of this kernel differ only in N, so the ratio carries over
-                ratio = 671.8 / 671.2
-                out["roofline"]["traffic"] = round(ratio * out["roofline"]["algorithmic_mb_per_launch"] * 1e6)
-                out["roofline"]["traffic_pmc"] = {
-                    "instance": "N=640 64x64 C64->K64 3x3/1 (dgrad form, no prologue)", "fetch_size_x2_mb": 336.3,
-                    "write_size_mb": 335.5, "traffic_mb": 671.8, "algorithmic_mb": 671.2, "ratio": round(ratio, 3),
-                    "unit_of_traffic": "bytes per launch = ratio x algorithmic bytes of the average launch",
-                    "source": "profiles/r01_e_pmc_layer2_traffic.md"}
+            pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
+            if os.path.exists(pmc):
+                for e in json.load(open(pmc))["kernels"]:
+                    if e["match"] in d["name"]:
+                        # ratio = PMC traffic / algorithmic bytes over the shapes this kernel runs in the step, weighted by
+                        # the step's launch mix; the launches differ from the measured ones only in N (640 vs 448)
+                        out["roofline"]["traffic"] = round(e["ratio"] * out["roofline"]["algorithmic_mb_per_launch"] * 1e6)
+                        out["roofline"]["traffic_pmc"] = {
+                            "ratio": e["ratio"], "shapes": e["shapes"], "launch_mix": e["bench_mix"],
+                            "unit_of_traffic": "bytes per launch = ratio x algorithmic bytes of the average launch",
+                            "source": "profiles/r01_g_pmc_traffic.json"}
+                        break
             out["conv_kernels"] = [{"kernel": r["name"], "launches_per_step": r["launches"] // nprof,
                                     "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
                                     "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
