@@ -126,7 +126,11 @@ __device__ __forceinline__ void stem_commit4(T* halo, const StemRaw& r) {
 template <typename T, bool INF32>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int tiles_h, int tiles_w, int ntiles) {
   constexpr bool BF = Elem<T>::DT == DT_BF16;
-  constexpr int WROW = 224 * sizeof(T) + 16;     // padded weight row: odd number of 16-byte slots
+  // bf16: unpadded 448-byte rows with the 16-byte chunk index XORed with ((k >> 3) & 2).  A lane group of a ds_read_b128
+  // holds rows {0-3, 24-27 | 8-11, 16-19} (+ tile offsets) of two k-chunks; with any row PADDING two of them share a bank
+  // slot (2-way conflict on every weight read = 44 % of the kernel's LDS cycles by SQ_LDS_BANK_CONFLICT); this swizzle is
+  // conflict-free (enumerated over all tiles / filter rows / lane groups) and costs nothing: for a lane it is g ^ 2*(li>>3)
+  constexpr int WROW = BF ? 224 * (int)sizeof(T) : 224 * (int)sizeof(T) + 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* w_lds = smem;
   T* halo0 = reinterpret_cast<T*>(smem + 64 * WROW);     // two halo buffers of HR*HC*4 elements
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
     constexpr int CH = 224 * sizeof(T) / 16;     // 16-byte chunks per row
     for (int i = tid; i < 64 * CH; i += 256) {
       const int k = i / CH, c = i - k * CH;
-      st16(w_lds + k * WROW + c * 16, ld16(wg + (size_t)i * 16));
+      st16(w_lds + k * WROW + (BF ? (c ^ ((k >> 3) & 2)) : c) * 16, ld16(wg + (size_t)i * 16));
     }
     for (int i = tid; i < 2 * HR * HC * 4; i += 256) Elem<T>::st(halo0 + i, 0.f);
   }
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int k = STEM_CH(t, li >> 2, li & 3);
-          af[t] = ld16(w_lds + k * WROW + (r * 8 + 2 * g) * 4 * sizeof(T));
+          af[t] = ld16(w_lds + k * WROW + (r * 8 + 2 * (g ^ ((li >> 3) << 1))) * 4 * sizeof(T));
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
