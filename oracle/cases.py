@@ -29,6 +29,11 @@ CASES = {
                        lambda_u=1.0, opt="adam"),
     "bpq_cr_f0": dict(script="bpq_cr", hw=256, b=1, mu=2, nb=2, modules=0, classes=1, lr=1e-4, wd=1e-4,
                       lambda_u=1.0, opt="adam"),
+    # the BASELINE.json / bench.py workload itself, ONE iteration: per-GPU --batch_size 64 --mu 7, full fine-tune
+    # (student 192 + 448 images, teacher 448).  Its golden holds reductions only (losses, feature sums, per-parameter
+    # gradient norms and seeded +-1 projections), see tests/golden/make_golden.py:gen_bpq_cr_full
+    "bpq_cr_full": dict(script="bpq_cr", hw=256, b=64, mu=7, nb=1, modules=0, classes=1, lr=1e-4, wd=1e-4,
+                        lambda_u=1.0, opt="adam"),
     # eval_Camelyon_SSL_CR.train: CE + hard pseudo-label CE, SGD-Nesterov lr 5e-4 (:251-256,514)
     "cam_cr_f60": dict(script="cam_cr", hw=64, b=2, mu=2, nb=2, modules=60, classes=2, lr=5e-4, wd=1e-4,
                        lambda_u=1.0, opt="sgd"),
@@ -49,6 +54,11 @@ CASES = {
 }
 
 PARAM_SEED = 42        # the reference's default --seed (eval_BreastPathQ_SSL_CR.py:253)
+
+
+def grad_probe(idx, numel):
+    """seeded +-1 vector for parameter idx: <grad, probe> pins the DIRECTION of a gradient in one float"""
+    return torch.from_numpy(np.random.RandomState(9000 + idx).randint(0, 2, numel).astype(np.float64) * 2.0 - 1.0)
 
 
 def labeled_batches(case, seed0=1000):

@@ -120,6 +120,91 @@ def test_bpq_cr_epoch_vs_reference(name, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_bpq_cr_full_size_step_vs_reference(dtype):
+    """The BASELINE.json / bench.py workload at FULL size (student 192+448, teacher 448 images of 256x256, full
+    fine-tune, Adam) against reductions of the reference's own iteration (tests/golden/make_golden.py:gen_bpq_cr_full):
+    returned loss averages, feature-matrix row norms / column sums, the post-step state snapshot, and EVERY parameter
+    gradient through its L2 norm and a seeded +-1 projection (the reference's .grad after its own backward).
+    fp32 mode: 1e-3 on losses/features (north-star tolerance).  Gradients: at this size the early-layer gradients are sums
+    of 640 per-image terms that largely cancel, and the golden's FLOAT64 run of the same iteration shows the reference's
+    own fp32 .grad to be 3.5e-3..4.8e-3 (relative L2, per parameter: grad_ref32_err) away from the exact gradient there.
+    So the engine is measured against the float64 reductions and held to max(3e-3, 3 x the reference's own fp32 error) per
+    parameter.  bf16 mode: 6e-2 on losses/features; gradients are held to 2 x the error that bf16 STORAGE alone causes in a
+    CPU emulation of the same iteration (grad_bf16emul_err, oracle/bf16_emul.py: 20-45 % in the early layers of this
+    random-weight, loss ~1e3 problem, cosine ~0.9) + 0.05 -- the rule of test_gradients_vs_oracle, at full size (the
+    engine's bf16 error profile matches the emulation's: 0.45 at conv1, 0.19 at layer4.0.conv1, 0.004 at fc.0)."""
+    from ssl_cr_histo_amd import steps
+    eng = _engine(dtype)
+    name = "bpq_cr_full"
+    c = C.CASES[name]
+    g = load_golden(name)
+
+    def fresh():
+        mt, ct = build("finetune", "finetune", 1, True)
+        ms, cs = build("finetune", "finetune", 1, True)
+        freeze(mt, 64)
+        freeze(ms, c["modules"])
+        return mt, ct, ms, cs
+
+    # ---- (1) the epoch function, as the reference script calls it
+    mt, ct, ms, cs = fresh()
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())), lr=c["lr"],
+                           betas=(0.9, 0.999), weight_decay=c["wd"])
+    ret = steps.bpq_cr_train(ns(lambda_u=c["lambda_u"]), mt, ms, ct, cs, C.labeled_batches(name), C.unlabeled_batches(name), opt, 1)
+    ts, tf, tp = TOLS[dtype]
+    for i in range(3):
+        assert abs(ret[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i]), (i, ret[i], g[f"{name}/ret"][i])
+    f = ret[3].cpu().double()
+    assert f.shape == (c["b"] * 3 + c["b"] * c["mu"], 768)
+    assert rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]) < tf
+    assert rel_err(f.sum(0), g[f"{name}/feats_colsum"]) < tf
+    assert rel_err(ret[3][:4].cpu(), g[f"{name}/feats_head"]) < tf
+    assert torch.equal(ret[4].cpu(), torch.from_numpy(g[f"{name}/targets"]))
+    if dtype == "fp32":
+        check_snapshot(g, name, state_of(ms, cs), tp)
+
+    # ---- (2) the gradients of that iteration (fresh weights, no update in between)
+    mt, ct, ms, cs = fresh()
+    (xl, yl), = C.labeled_batches(name)
+    (uw, us), = C.unlabeled_batches(name)
+    te, st = eng.bind(mt, ct), eng.bind(ms, cs)
+    mt.eval()
+    ms.train()
+    hw = c["hw"]
+    eng.step_ssl_cr(te, st, "mse", xl.reshape(-1, 3, hw, hw), yl.reshape(-1), uw, us, c["lambda_u"])
+    names = [str(n) for n in g[f"{name}/grad_names"]]
+    mine = [k for k, _ in list(ms.named_parameters()) + list(cs.named_parameters())]
+    assert names == mine, "parameter order differs from the reference's named_parameters()"
+    l2_ref, pr_ref, ref_err = g[f"{name}/grad_l2_f64"], g[f"{name}/grad_probe_f64"], g[f"{name}/grad_ref32_err"]
+    rows, bad = [], []
+    for i, k in enumerate(names):
+        gr = st.grad(i).cpu().double().reshape(-1)
+        e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
+        e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
+        tol_l2 = tol_pr = max(3e-3, 3.0 * ref_err[i])
+        if dtype == "bf16":
+            # a single +-1 projection of an error vector e is ~N(0, |e|^2): 3.5 sigma for the projection, 2x for the norm
+            tol_l2 = 2.0 * g[f"{name}/grad_bf16emul_err"][i] + 0.05
+            tol_pr = 3.5 * g[f"{name}/grad_bf16emul_err"][i] + 0.05
+        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}  "
+                    f"(reference fp32: {ref_err[i]:.2e}, bound {tol_pr:.1e})")
+        if e_l2 > tol_l2 or e_pr > tol_pr:
+            bad.append(rows[-1])
+    print(f"[{dtype}] full-size gradients vs the float64 run of the same iteration:\n" + "\n".join(rows))
+    assert not bad, "\n".join(bad)
+    assert abs(float(g[f"{name}/loss_f64"][0]) - g[f"{name}/ret"][0]) <= 1e-5 * g[f"{name}/ret"][0]     # one batch: average == the loss
+    for key in g.files:
+        if key.startswith(f"{name}/grad/"):
+            k = key[len(name) + 6:]
+            want = torch.from_numpy(g[key]).double()
+            idx = names.index(k)
+            got = st.grad(idx).cpu().double().reshape(want.shape)
+            # full small tensors against the reference's fp32 .grad: two fp32 results, each ref_err from the exact one
+            bound = 3e-3 + 2.5 * ref_err[idx] if dtype == "fp32" else 2.0 * g[f"{name}/grad_bf16emul_err"][idx] + 0.05
+            assert rel_err(got, want) < bound, (k, rel_err(got, want), bound)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["cam_cr_f60", "cam_cr_f0"])
 def test_cam_cr_epoch_vs_reference(name, dtype):
     from ssl_cr_histo_amd import steps
