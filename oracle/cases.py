@@ -44,6 +44,9 @@ CASES = {
                          lambda_u=1.0, opt="adam"),
     # pretrain_BreastPathQ.train/validate: RSP 6-way CE, SGD-Nesterov lr .01 + Lookahead(5,.5) (:245-247)
     "rsp": dict(script="rsp", hw=64, b=4, nb=2, classes=6, lr=0.01, wd=1e-4, opt="sgd"),
+    # one RSP iteration at full size (pretrain_BreastPathQ.py defaults: --batch_size 128, 256x256 tiles; 3 x 128 images);
+    # golden = reductions only, tests/golden/make_golden.py:gen_rsp_full
+    "rsp_full": dict(script="rsp", hw=256, b=128, nb=1, classes=6, lr=0.01, wd=1e-4, opt="sgd"),
     # eval_Camelyon_SSL.train: supervised CE (student only), SGD-Nesterov (:371)
     "cam_sup": dict(script="cam_sup", hw=64, b=2, nb=2, modules=0, classes=2, lr=1e-3, wd=1e-4, opt="sgd"),
     # eval_BreastPathQ_SSL.train: supervised MSE, Adam (:396); image side is args.image_size (:58)

@@ -266,6 +266,36 @@ def gen_rsp(name, out):
     snapshot(name + "/la5", model, cls, out)
 
 
+def gen_rsp_full(name, out):
+    """one iteration of pretrain_BreastPathQ.train at its default batch (3 x 128 images of 256x256): loss/acc, reductions of
+    the feature matrix, per-parameter gradient norm + seeded +-1 projection of the reference's .grad, post-step snapshot."""
+    c = C.CASES[name]
+    m = importlib.import_module("pretrain_BreastPathQ")
+    model, cls = build("triplet", "mlp", 6)
+    crit = torch.nn.CrossEntropyLoss()
+    opt = torch.optim.SGD(list(model.parameters()) + list(cls.parameters()), lr=c["lr"], momentum=0.9,
+                          weight_decay=c["wd"], nesterov=True)
+    a = args_ns(tile_h=c["hw"], tile_w=c["hw"])
+    ret = m.train(a, model, cls, C.rsp_batches(name), crit, opt, 1)
+    out[f"{name}/ret"] = np.array(ret[:2], dtype=np.float64)
+    f = ret[2].double()
+    out[f"{name}/feats_shape"] = np.array(f.shape)
+    out[f"{name}/feats_rowl2"] = f.norm(dim=1).numpy()
+    out[f"{name}/feats_colsum"] = f.sum(0).numpy()
+    out[f"{name}/feats_head"] = ret[2][:4].numpy()
+    out[f"{name}/targets"] = ret[3].numpy()
+    names, l2, pr = [], [], []
+    for i, (k, p) in enumerate(list(model.named_parameters()) + list(cls.named_parameters())):
+        g = p.grad.detach().double().reshape(-1)
+        names.append(k)
+        l2.append(float(g.norm()))
+        pr.append(float((g * C.grad_probe(i, g.numel())).sum()))
+    out[f"{name}/grad_names"] = np.array(names)
+    out[f"{name}/grad_l2"] = np.array(l2)
+    out[f"{name}/grad_probe"] = np.array(pr)
+    snapshot(name, model, cls, out)
+
+
 def gen_cam_sup(name, out):
     c = C.CASES[name]
     m = importlib.import_module("eval_Camelyon_SSL")
@@ -333,7 +363,7 @@ def gen_stages(out):
 def main():
     gens = {"bpq_cr_f60": gen_bpq_cr, "bpq_cr_f0": gen_bpq_cr, "cam_cr_f60": gen_cam_cr, "cam_cr_f0": gen_cam_cr,
             "kather_cr_f0": gen_kather_cr, "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup,
-            "cam_wsi": gen_cam_wsi, "bpq_cr_full": gen_bpq_cr_full}
+            "cam_wsi": gen_cam_wsi, "bpq_cr_full": gen_bpq_cr_full, "rsp_full": gen_rsp_full}
     only = sys.argv[1:]
     for name, fn in gens.items():
         if only and name not in only:

@@ -309,6 +309,62 @@ def test_rsp_epoch_and_lookahead_vs_reference(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_rsp_full_size_step_vs_reference(dtype):
+    """One RSP pre-training iteration at the reference's default size (pretrain_BreastPathQ.py --batch_size 128: 3 x 128
+    images of 256x256 through the shared TripletNet backbone, 6-way CE, SGD-Nesterov) against reductions of the reference's
+    own iteration: loss / accuracy, feature row norms and column sums, post-step snapshot, and every parameter gradient
+    through its L2 norm and a seeded +-1 projection of the reference's .grad.  fp32: 1e-3 on loss/features, 5e-3 / 2e-2 per
+    gradient norm / projection (two fp32 implementations at this size, cf. the float64 yardstick of the SSL_CR full-size case);
+    bf16: 6e-2 on loss, 0.2 on features, gradient norms within 0.35 (storage noise, see oracle/bf16_emul.py)."""
+    from ssl_cr_histo_amd import steps
+    eng = _engine(dtype)
+    name = "rsp_full"
+    c = C.CASES[name]
+    g = load_golden(name)
+    model, cls = build("triplet", "mlp", 6, False)
+    opt = torch.optim.SGD(list(model.parameters()) + list(cls.parameters()), lr=c["lr"], momentum=0.9, weight_decay=c["wd"],
+                          nesterov=True)
+    a = ns(tile_h=c["hw"], tile_w=c["hw"])
+    ret = steps.rsp_train(a, model, cls, C.rsp_batches(name), torch.nn.CrossEntropyLoss(), opt, 1)
+    ts, tf, tp = TOLS[dtype]
+    assert abs(ret[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0], (ret[0], g[f"{name}/ret"][0])
+    f = ret[2].cpu().double()
+    assert list(f.shape) == list(g[f"{name}/feats_shape"])
+    tfe = tf if dtype == "fp32" else 0.2
+    assert rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]) < tfe
+    assert rel_err(f.sum(0), g[f"{name}/feats_colsum"]) < tfe
+    assert rel_err(ret[2][:4].cpu(), g[f"{name}/feats_head"]) < tfe
+    assert torch.equal(ret[3].cpu(), torch.from_numpy(g[f"{name}/targets"]))
+    if dtype == "fp32":
+        assert abs(ret[1] - g[f"{name}/ret"][1]) <= 100.0 / c["b"] + 1e-9      # accuracy in percent: at most one flipped prediction
+        check_snapshot(g, name, state_of(model, cls), tp)
+    # gradients of that iteration: fresh weights, the engine's step without the update
+    model, cls = build("triplet", "mlp", 6, False)
+    net_ = eng.bind(model, cls)
+    model.train()
+    cls.train()
+    (i1, i2, i3, tgt), = C.rsp_batches(name)
+    hw = c["hw"]
+    eng.step_supervised(net_, "ce", [v.reshape(-1, 3, hw, hw) for v in (i1, i2, i3)], tgt.long().reshape(-1), train=True)
+    names = [str(n) for n in g[f"{name}/grad_names"]]
+    mine = [k for k, _ in list(model.named_parameters()) + list(cls.named_parameters())]
+    assert names == mine
+    l2_ref, pr_ref = g[f"{name}/grad_l2"], g[f"{name}/grad_probe"]
+    # fp32: norm 5e-3, projection 2e-2 (two fp32 runs, each ~4e-3 from the exact gradient at this size; a projection is ~3 sigma)
+    tol_l2, tol_pr = (5e-3, 2e-2) if dtype == "fp32" else (0.35, 1.5)
+    rows, bad = [], []
+    for i, k in enumerate(names):
+        gr = net_.grad(i).cpu().double().reshape(-1)
+        e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
+        e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
+        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}")
+        if e_l2 > tol_l2 or e_pr > tol_pr:
+            bad.append(rows[-1])
+    print(f"[{dtype}] RSP full-size gradients vs the reference's .grad:\n" + "\n".join(rows))
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_supervised_epochs_vs_reference(dtype):
     from ssl_cr_histo_amd import steps
     _engine(dtype)
