@@ -166,6 +166,10 @@ typedef struct sslcr_tensor_desc {
   float* p; float* g; float* s1; float* s2;
   int n;
   int K, C, RS;           /* conv weight: g is [K][RS][C] while p/s1/s2 are [K][C][RS] ; K=0: same layout */
+  void* w_fwd;            /* optional (K > 0): the update also writes the conv kernels' shadow weights of the new value -- */
+  void* w_dgrad;          /* forward pack [K][RS][C] and dgrad pack [C][RS][K] (sslcr_pack_conv layouts), element type pack_dtype */
+  int pack_dtype;         /* 0 fp32, 1 bf16 */
+  int dgrad_flip;         /* dgrad pack with the taps reversed (stride-1 3x3 dgrad runs as a plain conv of dY) */
 } sslcr_tensor_desc;
 typedef struct sslcr_opt_desc {
   int kind;               /* 0 adam, 1 sgd-nesterov */

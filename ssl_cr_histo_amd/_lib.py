@@ -52,7 +52,7 @@ LossDesc = _S("LossDesc", [("kind", i32), ("logits", vp), ("logits_t", vp), ("ta
                            ("dlogits", vp), ("out", vp), ("nx", i32), ("nu", i32), ("C", i32), ("lambda_u", f32),
                            ("inv_nx_global", f32), ("inv_nu_global", f32)])
 TensorDesc = _S("TensorDesc", [("p", vp), ("g", vp), ("s1", vp), ("s2", vp), ("n", i32), ("K", i32), ("C", i32),
-                               ("RS", i32)])
+                               ("RS", i32), ("w_fwd", vp), ("w_dgrad", vp), ("pack_dtype", i32), ("dgrad_flip", i32)])
 OptDesc = _S("OptDesc", [("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f32), ("eps", f32), ("wd", f32),
                          ("momentum", f32), ("bc1", f32), ("bc2", f32), ("first_step", i32), ("grad_scale", f32)])
 WeakAugDesc = _S("WeakAugDesc", [("src", vp), ("dst", vp), ("params", vp)] +

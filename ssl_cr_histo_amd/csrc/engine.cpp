@@ -149,7 +149,9 @@ struct sslcr_net {
   ConvL stem;
   BnL bn0;
   BlockL blocks[8];
-  DevBuf shadow, grads, heads, descs;
+  DevBuf shadow, grads, heads, descs, chunks;
+  int nchunks = 0;
+  bool opt_packs_all = false;     // the optimizer work list rewrites every non-stem conv's train-mode shadow weights
   size_t grad_count = 0;
   PassState pass[3];
   // heads state (fp32)
@@ -1040,6 +1042,8 @@ int sslcr_net_optimizer_step(sslcr_net* n, const sslcr_opt_desc* o, float* const
   if (rebuild) {
     n->host_descs.clear();
     n->max_n = 0;
+    std::vector<int2> host_chunks;
+    int packed_convs = 0;
     for (int i = 0; i < n->nparams; ++i) {
       if (!n->rg[i]) continue;
       if (!s1[i] || (o->kind == 0 && (!s2 || !s2[i]))) return fail("sslcr_net_optimizer_step: missing optimizer state for parameter %d", i);
@@ -1049,13 +1053,27 @@ int sslcr_net_optimizer_step(sslcr_net* n, const sslcr_opt_desc* o, float* const
       for (int b = 0; b < 8; ++b) {
         BlockL& B = n->blocks[b];
         const ConvL* L = B.c1.pidx == i ? &B.c1 : B.c2.pidx == i ? &B.c2 : (B.has_ds && B.ds.pidx == i) ? &B.ds : nullptr;
-        if (L) { t.K = L->cout; t.C = L->cin; t.RS = L->k * L->k; }
+        if (L) {
+          t.K = L->cout; t.C = L->cin; t.RS = L->k * L->k;
+          // the update writes the train-mode shadow weights of the new value (what pack_conv_layer(mode 1) would produce)
+          t.w_fwd = L->w_fwd; t.w_dgrad = L->w_dg; t.pack_dtype = n->ctx->dtype; t.dgrad_flip = (L->k == 3 && L->stride == 1);
+          ++packed_convs;
+        }
       }
+      // work list: OPT_CHUNK elements per entry
+      const int ti = (int)n->host_descs.size();
+      for (int e = 0; e < t.n; e += OPT_CHUNK) host_chunks.push_back({ti, e});
       n->host_descs.push_back(t);
       if (t.n > n->max_n) n->max_n = t.n;
     }
     n->ndesc = (int)n->host_descs.size();
     if (n->ndesc == 0) return 0;
+    int total_convs = 0;
+    for (int b = 0; b < 8; ++b) total_convs += n->blocks[b].has_ds ? 3 : 2;
+    n->opt_packs_all = packed_convs == total_convs;
+    n->nchunks = (int)host_chunks.size();
+    TRYI(n->chunks.ensure(host_chunks.size() * sizeof(int2)));
+    TRY(hipMemcpyAsync(n->chunks.p, host_chunks.data(), host_chunks.size() * sizeof(int2), hipMemcpyHostToDevice, st));
     TRYI(n->descs.ensure(n->ndesc * sizeof(sslcr_tensor_desc)));
     TRY(hipMemcpyAsync(n->descs.p, n->host_descs.data(), n->ndesc * sizeof(sslcr_tensor_desc), hipMemcpyHostToDevice, st));
     TRY(hipStreamSynchronize(st));       // host_descs may be rebuilt before the copy would otherwise land
@@ -1064,8 +1082,13 @@ int sslcr_net_optimizer_step(sslcr_net* n, const sslcr_opt_desc* o, float* const
   }
   if (n->ndesc == 0) return 0;
   // sharded runs: every rank's loss is already scaled by 1/(global batch), so the all-reduced SUM is the exact gradient
-  TRY(launch_optimizer((const sslcr_tensor_desc*)n->descs.p, n->ndesc, n->max_n, *o, st));
+  TRY(launch_optimizer_chunks((const sslcr_tensor_desc*)n->descs.p, n->chunks.p, n->nchunks, *o, st));
   n->packed_train = false; n->packed_eval = false;
+  if (n->opt_packs_all) {
+    // every block conv's shadow weights were rewritten with the update; only the stem's (its own K order) are left
+    TRYI(pack_conv_layer(n, n->stem, n->bn0, 1, st));
+    n->packed_train = true;
+  }
   return 0;
 }
 

@@ -442,6 +442,8 @@ def test_optimizer_and_pack(kind):
     dev_p = [p.to(DEV).contiguous() for p in ps]
     s1 = [torch.zeros_like(p) for p in dev_p]
     s2 = [torch.zeros_like(p) for p in dev_p]
+    sh_f = torch.zeros((128, 3, 3, 64), dtype=torch.bfloat16, device=DEV)
+    sh_d = torch.zeros((64, 3, 3, 128), dtype=torch.bfloat16, device=DEV)
     for step in range(1, 4):
         grads = [rnd(100 * step + i, s) for i, s in enumerate(shapes)]
         dev_g = []
@@ -455,6 +457,8 @@ def test_optimizer_and_pack(kind):
                 Kk, Cc, RS = 0, 0, 0
             dev_g.append(gd)
             descs[i] = L.TensorDesc(L.ptr(p), L.ptr(gd), L.ptr(s1[i]), L.ptr(s2[i]), p.numel(), Kk, Cc, RS)
+            if i == 1:            # the update also writes this conv's shadow weights (bf16 forward pack, flipped dgrad pack)
+                descs[i].w_fwd, descs[i].w_dgrad, descs[i].pack_dtype, descs[i].dgrad_flip = L.ptr(sh_f), L.ptr(sh_d), 1, 1
         dd = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(DEV)
         o = L.OptDesc(0 if kind == "adam" else 1, 1e-2, 0.9, 0.999, 1e-8, 1e-4, 0.9, 1 - 0.9 ** step, 1 - 0.999 ** step,
                       int(step == 1), 1.0)
@@ -464,6 +468,8 @@ def test_optimizer_and_pack(kind):
         opt.step()
     for p, r in zip(dev_p, ref):
         close(p, r, 2e-5, f"{kind} param")
+    wf1, wd1, _ = K.pack_conv(dev_p[1], 1, fwd=True, dgrad=True, dgrad_flip=True)
+    assert torch.equal(sh_f, wf1) and torch.equal(sh_d, wd1), "shadow weights written by the update != pack of the updated parameter"
     # pack: layouts and folding
     w = rnd(90, (128, 64, 3, 3), 0.05)
     wf, wd, _ = K.pack_conv(w.to(DEV), 0, fwd=True, dgrad=True)
