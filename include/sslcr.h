@@ -139,6 +139,8 @@ typedef struct sslcr_bn_bwd_desc {
   int g_in_reduce;        /* with yact and gout: the REDUCE pass writes the masked gradient g = dy * (yact > 0) to gout, and the
                              apply pass reads it back instead of dy and yact (one tensor read less; the identity path of a
                              residual block needs g anyway).  Not with pool_dy. */
+  float* dgamma; float* dbeta;   /* optional: the apply pass also accumulates the affine gradients (what sslcr_bn_param_grads does: */
+  float pg_scale;                /*   dgamma += pg_scale * sums[1] * invstd, dbeta += pg_scale * sums[0]) -- one launch less per BatchNorm */
 } sslcr_bn_bwd_desc;
 int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream);

@@ -453,6 +453,15 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, const flo
   }
 }
 
+// affine gradients from the finished sums, by workgroup 0 of the apply pass (same arithmetic as bn_param_grads_kernel)
+__device__ __forceinline__ void bn_bwd_param_grads(const BnBwdArgs& a) {
+  if (blockIdx.x != 0 || !a.dgamma || !a.dbeta) return;
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    a.dgamma[c] += (float)(a.sums[a.C + c] * (double)a.invstd[c] * (double)a.pg_scale);
+    a.dbeta[c] += (float)(a.sums[c] * (double)a.pg_scale);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   constexpr int EPC = Elem<T>::EPC;
@@ -508,6 +517,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     cC[e] = -sc * m0 - cB[e] * a.mean[c];
     rsc[e] = sc; rsh[e] = a.shift[c];
   }
+  bn_bwd_param_grads(a);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float g[EPC], xf[EPC], d[EPC];
     bn_bwd_g<T>(a, i, rsc, rsh, g, xf);
@@ -599,6 +609,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const BnBwdArgs 
     cC[e] = -sc * m0 - cB[e] * a.mean[c];
     rsh[e] = a.shift[c];
   }
+  bn_bwd_param_grads(a);
   const char* xg = reinterpret_cast<const char*>(a.x);
   const char* dyg = reinterpret_cast<const char*>(a.pool_dy);
   char* dxg = reinterpret_cast<char*>(a.dx);

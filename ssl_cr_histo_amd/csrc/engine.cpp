@@ -624,6 +624,13 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
   a.dy = dy; a.x = x; a.yact = yact; a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
   a.sums = c->bn_sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
   a.g_in_reduce = (g_in_reduce && yact && gout) ? 1 : 0;
+  if (n->rg[bn.pg] || n->rg[bn.pb]) {
+    // dgamma/dbeta ride on the apply pass.  Synced BN: every rank holds the GLOBAL sums and the gradient all-reduce adds
+    // `world` copies -> pre-divide (per-replica BN: the sums are this rank's share, the gradient all-reduce adds them up)
+    a.dgamma = gptr(n, bn.pg); a.dbeta = gptr(n, bn.pb);
+    a.pg_scale = (c->comm && c->bn_sync) ? 1.0f / c->world : 1.0f;
+    if (!a.dgamma || !a.dbeta) { a.dgamma = nullptr; a.dbeta = nullptr; }
+  }
   if (pool) { a.pool_dy = pool->dy; a.pool_argmax = pool->argmax; a.pH = pool->H; a.pW = pool->W; a.pOH = pool->OH; a.pOW = pool->OW; a.pool_y = pool->y; }
   const bool synced = c->comm && c->bn_sync;
   a.count = synced ? count * c->world : count;
@@ -647,14 +654,6 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
     TRY(e);
   } else {
     TRY(launch_bn_bwd_apply(c->dtype, a, st));
-  }
-  if (n->rg[bn.pg] || n->rg[bn.pb]) {
-    // dgamma/dbeta: with synced BN the sums are already global -> scale so that the later grad all-reduce(sum)/world is right
-    float* dg = gptr(n, bn.pg);
-    float* db = gptr(n, bn.pb);
-    // synced BN: every rank holds the GLOBAL sums and the gradient all-reduce adds `world` copies -> pre-divide
-    // (per-replica BN: the sums are this rank's share, the gradient all-reduce adds them up)
-    if (dg && db) TRY(launch_bn_param_grads_scaled(c->bn_sums, sv.invstd, dg, db, bn.C, synced ? 1.0f / c->world : 1.0f, st));
   }
   return 0;
 }
