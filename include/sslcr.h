@@ -45,6 +45,12 @@ typedef struct sslcr_conv_desc {
   int pix_mul, pix_off_h, pix_off_w;   /* sub-lattice of the pixel space: pixel (i,j) of the PH x PW grid is (i*mul+off_h, j*mul+off_w);
                                           mul = 0 means 1.  With tap_mask this runs ONE parity class of a strided dgrad */
   unsigned tap_mask;                   /* bit (r*S+s) set = visit that tap; 0 = all taps */
+  /* BatchNorm-backward front end of a dgrad (optional; needs stats, excludes in_scale / bias / residual / relu; 3x3 stride 1 on
+     16x16-tileable maps only -- sslcr_conv2d fails otherwise).  y is the gradient w.r.t. relu(bn(mask_x)); with these set the
+     kernel writes g = y * (mask_scale[k]*mask_x + mask_shift[k] > 0) instead of y, and the stats rows hold
+     (sum g, sum g*(mask_x - mask_mean[k])) -- the two sums of sslcr_bn_bwd_reduce -- instead of (sum y, sum y^2): the reduce
+     pass over (dy, x) of that BatchNorm is not needed. */
+  const void* mask_x; const float* mask_scale; const float* mask_shift; const float* mask_mean;
 } sslcr_conv_desc;
 int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream);
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d);

@@ -96,7 +96,14 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   // the (folded-BatchNorm) bias of all K outputs: read from LDS in the epilogue.  As global loads -- even skipped ones, when
   // there is no bias -- they put a compiler vmcnt(0) in front of the output stores
   float* s_bias = s_stat + 8 * BKO;
-  for (int i = tid; i < a.K; i += NT) s_bias[i] = a.bias ? a.bias[i] : 0.f;
+  // BatchNorm-backward front end (sslcr_conv_desc.mask_x): s_bias holds the BatchNorm's scale, two more arrays its shift and mean
+  const bool mk = !XF && a.mask_x != nullptr;
+  float* s_msh = s_bias + a.K;
+  float* s_mmu = s_msh + a.K;
+  for (int i = tid; i < a.K; i += NT) {
+    s_bias[i] = mk ? a.mask_scale[i] : (a.bias ? a.bias[i] : 0.f);
+    if (mk) { s_msh[i] = a.mask_shift[i]; s_mmu[i] = a.mask_mean[i]; }
+  }
   const float relu_lo = a.in_relu ? 0.f : -__builtin_inff();
 
   // XCD-aware walk: blocks land on XCD (blockIdx % 8); each XCD takes a contiguous run of tiles per round so that
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   char* yg = reinterpret_cast<char*>(a.y);
   // no residual with an input transform (conv_h16_ok): a residual load in the epilogue -- even one skipped at run time --
   // made the compiler put a vmcnt(0) in front of every output store, i.e. eight serial write round trips per item
-  const char* rg = XF ? nullptr : reinterpret_cast<const char*>(a.residual);
+  const char* rg = XF ? nullptr : reinterpret_cast<const char*>(a.mask_x ? a.mask_x : a.residual);   // same shape, same prefetch
   // bf16 residual (teacher conv2 / the skip gradient of a block's first dgrad): requested with the next halo in the middle
   // of the item's LAST stage, so its HBM round trip sits under six steps of MFMAs instead of in front of the epilogue
   // (the epilogue-time load cost 57-80 us per layer1 launch, one exposed latency per tile)
@@ -352,6 +359,39 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
     if (last) {
       // ---------------- epilogue of the finished item; its stores drain under the next item's taps
       const int kb = cur.k0 + wk * (BKO / WK) + g * (4 * TK);
+      float s1[4 * TK], s2[4 * TK];
+      if (mk) {
+        // g = y * (scale*x + shift > 0) ; partial sums of g and g*(x - mean) over this wave's 64 pixels
+        // one 16-byte chunk of channels at a time: its 3 x EPC constants live only while the four pixel rows are processed
+#pragma unroll
+        for (int q = 0; q < 4 * TK / EPC; ++q) {
+          float msc[EPC], msh[EPC], mmu[EPC], a1[EPC], a2[EPC];
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            msc[e] = s_bias[kb + q * EPC + e]; msh[e] = s_msh[kb + q * EPC + e]; mmu[e] = s_mmu[kb + q * EPC + e];
+            a1[e] = 0.f; a2[e] = 0.f;
+          }
+#pragma unroll
+          for (int p = 0; p < TP; ++p) {
+            const size_t off = out_off(cur, p);
+            float xr[EPC], vq[EPC];
+            if constexpr (RPRE) Elem<T>::unpack(rres[p][q], xr);
+            else Elem<T>::unpack(ld16(rg + off + q * 16), xr);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              const int idx = q * EPC + e;
+              const float y = acc[idx >> 2][p][idx & 3];
+              const float gv = fmaf(xr[e], msc[e], msh[e]) > 0.f ? y : 0.f;
+              vq[e] = gv;
+              a1[e] += gv;
+              a2[e] = fmaf(gv, xr[e] - mmu[e], a2[e]);
+            }
+            st16(yg + off + q * 16, PackH<T>::run(vq));
+          }
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { s1[q * EPC + e] = row16_sum(a1[e]); s2[q * EPC + e] = row16_sum(a2[e]); }
+        }
+      } else {
       float bias[4 * TK];
 #pragma unroll
       for (int j = 0; j < 4 * TK; ++j) bias[j] = s_bias[kb + j];
@@ -381,7 +421,6 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
         }
       }
       if (a.stats) {
-        float s1[4 * TK], s2[4 * TK];
 #pragma unroll
         for (int t = 0; t < TK; ++t)
 #pragma unroll
@@ -392,6 +431,9 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
             s1[t * 4 + j] = row16_sum(x1);
             s2[t * 4 + j] = row16_sum(x2);
           }
+      }
+      }
+      if (a.stats) {
         if (li == 0) {
           float* sp = s_stat + (wp * 2) * BKO + wk * (BKO / WK) + g * (4 * TK);
 #pragma unroll
@@ -444,6 +486,11 @@ static int device_cus() {
 
 bool conv_h16_ok(int dtype, const ConvArgs& a) {
   if (a.in_scale && a.residual) return false;          // not a ResNet combination; the older halo kernels take it
+  if (a.mask_x) {
+    // (a.stats is checked at launch: sslcr_conv2d_partial_rows asks before the rows buffer exists)
+    if (!a.mask_scale || !a.mask_shift || !a.mask_mean || a.in_scale || a.bias || a.residual || a.relu) return false;
+    if (18 * 24 * 128 + 2 * 3 * (a.K % 128 == 0 ? 128 : 64) * 128 + 2 * a.C * 4 + 8 * 128 * 4 + 3 * a.K * 4 > 160 * 1024) return false;
+  }
   return conv_halo256_mode(dtype, a) == 16 && conv_halo256_mode(DT_BF16, a) == 16;
 }
 // partial-statistics rows the launch will write: four per workgroup (see s_stat)
@@ -458,7 +505,8 @@ static bool h16_resident(const ConvArgs& a) { return a.C == 64 && a.K == 64; }
 
 template <typename T, int BKO, int WK, bool XF, bool WR = false>
 static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
-  const size_t lds = 18 * 24 * 128 + (WR ? 3 : 2) * 3 * BKO * 128 + 2 * a.C * sizeof(float) + 8 * BKO * sizeof(float) + a.K * sizeof(float);
+  const size_t lds = 18 * 24 * 128 + (WR ? 3 : 2) * 3 * BKO * 128 + 2 * a.C * sizeof(float) + 8 * BKO * sizeof(float) +
+                     (a.mask_x ? 3 : 1) * a.K * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   auto kern = conv3x3_h16_kernel<T, BKO, WK, XF, WR>;
   static bool attr_done = false;
@@ -484,6 +532,7 @@ static hipError_t launch_ht(const ConvArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_conv_h16(int dtype, const ConvArgs& a, hipStream_t st) {
+  if (a.mask_x && !a.stats) return hipErrorInvalidValue;
   return dtype == DT_BF16 ? launch_ht<bf16_t>(a, st) : launch_ht<float>(a, st);
 }
 

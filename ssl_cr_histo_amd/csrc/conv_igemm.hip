@@ -331,6 +331,7 @@ const char* conv_kernel_name(int dtype, const ConvArgs& a) {
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
   if (conv_h16_ok(dtype, a)) return launch_conv_h16(dtype, a, st);
+  if (a.mask_x) return hipErrorInvalidValue;        // the BatchNorm-backward front end exists in the 16x16-tile kernel only
   const int q = conv_halo256_mode(dtype, a);
   if (q && conv_halo256_mode(DT_BF16, a) == q) return launch_conv_halo256(dtype, a, q, st);
   const int tw = q ? 0 : conv_halo_tw(dtype, a);

@@ -617,7 +617,8 @@ struct PoolSrc {            // gradient arriving through the stem max-pool (see 
 };
 
 int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
-                void* dx, void* gout, size_t pixels, double count, hipStream_t st, const PoolSrc* pool = nullptr, int g_in_reduce = 0) {
+                void* dx, void* gout, size_t pixels, double count, hipStream_t st, const PoolSrc* pool = nullptr, int g_in_reduce = 0,
+                const float* sum_rows = nullptr, int n_sum_rows = 0) {
   sslcr_ctx* c = n->ctx;
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
@@ -634,8 +635,16 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
   if (pool) { a.pool_dy = pool->dy; a.pool_argmax = pool->argmax; a.pH = pool->H; a.pW = pool->W; a.pOH = pool->OH; a.pOW = pool->OW; a.pool_y = pool->y; }
   const bool synced = c->comm && c->bn_sync;
   a.count = synced ? count * c->world : count;
-  TRY(hipMemsetAsync(c->bn_sums, 0, 2 * bn.C * sizeof(double), st));
-  TRY(launch_bn_bwd_reduce(c->dtype, a, st));
+  if (sum_rows) {
+    // the dgrad that produced dy already left partial rows of (sum g, sum g (x - mean)) (sslcr_conv_desc.mask_x): rows -> sums
+    BnFinalizeArgs r;
+    memset(&r, 0, sizeof(r));
+    r.partials = sum_rows; r.rows = n_sum_rows; r.C = bn.C; r.stage = c->bn_stage; r.sums_out = c->bn_sums;
+    TRY(launch_bn_finalize(r, st));
+  } else {
+    TRY(hipMemsetAsync(c->bn_sums, 0, 2 * bn.C * sizeof(double), st));
+    TRY(launch_bn_bwd_reduce(c->dtype, a, st));
+  }
   if (synced) TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
   if (c->prof.on) {
     ProfRec r;
@@ -721,12 +730,25 @@ int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pa
     if (B.has_ds)
       TRYI(bn_backward(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st));
     TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
+    float* b1_rows = nullptr;
+    int b1_nrows = 0;
     {
       ConvArgs a = conv_args(B.c2, dRaw2, B.c2.w_dg, dAct1, N, oh, ow);      // dgrad 3x3/1: gather over dRaw2 [.,K] with [C][R][S][K]
       a.C = B.c2.cout; a.K = B.c2.cin; a.transposed = 0; a.PH = oh; a.PW = ow; a.OH = oh; a.OW = ow;   // flipped pack
+      // where the 16x16-tile kernel serves this dgrad it also applies bn1's ReLU mask and leaves bn1's two backward sums
+      // in its stats rows: bn1's reduce pass over (dAct1, raw1) is not run
+      ConvArgs m = a;
+      const BnSaved& s1 = ps.bn[B.b1.bidx];
+      m.mask_x = ps.blk[i].raw1; m.mask_scale = s1.scale; m.mask_shift = s1.shift; m.mask_mean = s1.mean;
+      if (conv_h16_ok(dt, m)) {
+        TRYI(ensure_partials(c, m, &b1_rows, &b1_nrows));
+        m.stats = b1_rows;
+        a = m;
+      }
       TRY(prof_conv(c, dt,a, st));
     }
-    TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, 1, dRaw1, nullptr, opix, (double)opix, st));
+    TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, b1_rows ? 0 : 1, dRaw1, nullptr, opix, (double)opix, st,
+                     nullptr, 0, b1_rows, b1_nrows));
     TRYI(wgrad_call(n, B.c1, X, dRaw1, nullptr, N, xh, xw, oh, ow, st));
     if (B.has_ds) TRYI(wgrad_call(n, B.ds, X, dRawD, nullptr, N, xh, xw, oh, ow, st));
     if (need_dx) {

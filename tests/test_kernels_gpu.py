@@ -230,6 +230,36 @@ def test_stem(shape, in_u8, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64), (5, 32, 32, 128, 128), (3, 16, 32, 128, 256), (70, 32, 32, 64, 64)])
+def test_conv_bn_backward_front_end(case, dtype):
+    """sslcr_conv_desc.mask_x: a 3x3/1 dgrad that also applies the ReLU mask of the BatchNorm it feeds and leaves that
+    BatchNorm's two backward sums in its stats rows -- against conv + mask + sums of the reference ops."""
+    K = _k()
+    N, H, W, C, Ko = case
+    x = q(rnd(81, (N, H, W, C)), dtype)
+    w = q(rnd(82, (Ko, 3, 3, C), 0.05), dtype)
+    xbn = q(rnd(83, (N, H, W, Ko), 2.0) + 0.3, dtype)
+    sc, sh, mu = rnd(84, (Ko,)), rnd(85, (Ko,)), rnd(86, (Ko,))
+    y, stats = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, want_stats=True,
+                        mask=(to_dev(xbn, dtype), sc.to(DEV), sh.to(DEV), mu.to(DEV)))
+    assert "conv3x3_h16_kernel" in K.last_conv_kernel, K.last_conv_kernel
+    want = R.conv_fwd(x, w, 1, 1)
+    keep = (xbn * sc + sh) > 0
+    g = want * keep
+    # elements within rounding of the mask threshold may legitimately flip: exclude |scale*x+shift| < 1e-6 from the comparison
+    edge = (xbn * sc + sh).abs() < 1e-6
+    close(torch.where(edge.to(DEV), torch.zeros_like(y), y), torch.where(edge, torch.zeros_like(g), g), TOL[dtype], "masked dgrad")
+    st = stats.double().sum(0).cpu()
+    close(st[0], g.double().sum((0, 1, 2)), 2e-4 if dtype == 0 else 3e-3, "sum g")
+    ref2 = (g.double() * (xbn.double() - mu.double())).sum((0, 1, 2))
+    close(st[1], ref2, 2e-4 if dtype == 0 else 3e-3, "sum g (x - mean)")
+    # a shape the 16x16-tile kernel does not serve must be refused, not silently served without the mask
+    with pytest.raises(Exception):
+        K.conv2d(to_dev(x[:, :15, :13].contiguous(), dtype), to_dev(w, dtype), 1, 1, want_stats=True,
+                 mask=(to_dev(xbn[:, :15, :13].contiguous(), dtype), sc.to(DEV), sh.to(DEV), mu.to(DEV)))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("in_u8", [True, False])
 @pytest.mark.parametrize("shape,split", [((5, 64, 64), 2), ((3, 30, 34), 1), ((4, 32, 32), 4)])
 def test_stem_two_segment_input(shape, split, in_u8, dtype):
