@@ -210,8 +210,9 @@ hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t*
 const char* wgrad_kernel_name(int dtype, const WgradArgs& a) {
   const bool bf = dtype == DT_BF16;
   const int tw = wgrad_halo_tw(a);
-  if (tw == 16) return bf ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 16>" : "sslcr::wgrad3x3_halo_kernel<float, 16>";
-  if (tw == 8) return bf ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 8>" : "sslcr::wgrad3x3_halo_kernel<float, 8>";
+  const bool wide = bf && a.K % 128 == 0;          // the 128-kout block, 8-wave form (wgrad_halo.hip)
+  if (tw == 16) return bf ? (wide ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 16, 2>" : "sslcr::wgrad3x3_halo_kernel<unsigned short, 16, 1>") : "sslcr::wgrad3x3_halo_kernel<float, 16, 1>";
+  if (tw == 8) return bf ? (wide ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 8, 2>" : "sslcr::wgrad3x3_halo_kernel<unsigned short, 8, 1>") : "sslcr::wgrad3x3_halo_kernel<float, 8, 1>";
   if (a.R == 3) return bf ? "sslcr::wgrad_kernel<unsigned short, 9>" : "sslcr::wgrad_kernel<float, 9>";
   return bf ? "sslcr::wgrad_kernel<unsigned short, 1>" : "sslcr::wgrad_kernel<float, 1>";
 }

@@ -22,8 +22,15 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
-template <typename T, int TW>
-__global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a, int tiles_per_split, int ntiles) {
+// KH = 1: a workgroup of four waves owns a 64(kout) x 64(cin) block, two workgroups share a CU and cover each other's staging
+//      phases (single LDS buffer).
+// KH = 2 (bf16, K % 128 == 0): eight waves own a 128(kout) x 64(cin) block -- wave = (cin tile, kout half).  The input halo
+//      and its producer-BatchNorm transform are staged once per 128 kouts instead of once per 64 (the halo is the operand
+//      that is re-read K/64 times: PMC traffic 2.3x / 3.4x algorithmic on layers 2 / 3), and with ONE workgroup per CU the
+//      (dY, halo) buffer is doubled: the next tile is transformed and written to the other buffer in the MIDDLE of this
+//      tile's MFMA loop, one barrier per tile.
+template <typename T, int TW, int KH>
+__global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradArgs a, int tiles_per_split, int ntiles) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int RB = 64 * sizeof(T);            // LDS bytes per pixel row (64 channels)
@@ -32,21 +39,26 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
   constexpr int NI = 128 / (TH * TW);
   constexpr int HH = TH + 2, HWD = TW + 2;
   constexpr int HP = NI * HH * HWD;             // 180 / 200 halo pixels staged per tile
-  constexpr int YL = 128 * CPR / 256;           // dY staging loads per thread (4 / 8)
-  constexpr int HL = (HP * CPR + 255) / 256;    // halo staging loads per thread
+  constexpr int NT = 256 * KH;
+  constexpr int YL = 128 * CPR / 256;           // dY staging loads per thread (4 / 8): 128 pixels x KH*64 kouts over NT threads
+  constexpr int HL = (HP * CPR + NT - 1) / NT;  // halo staging loads per thread
+  constexpr int YROWS = 256 / CPR, HROWS = NT / CPR;   // pixel rows covered per staging pass
   // bf16: halo rows are pitched to 24 (16-wide tiles) / 16 pixels -- multiples of 8 -- so that bits 1..2 of a halo pixel
   // index depend on the lane and the filter COLUMN only: the bank swizzle below is then a per-lane constant per column and
   // every transpose read is base register + immediate (3 + 4 address registers for all nine taps)
   constexpr int PITCH = BF ? (TW == 16 ? 24 : 16) : HWD;
-  constexpr int YBUF = 128 * RB, HBUF = NI * HH * PITCH * RB;
+  constexpr int YH = 128 * RB;                  // one 64-kout half of the dY tile
+  constexpr int YBUF = KH * YH, HBUF = NI * HH * PITCH * RB;
   constexpr int BUF = YBUF + HBUF;
-  constexpr int NBUF = 1;                       // single (dY, halo) buffer: two workgroups share a CU and cover each other's staging
+  constexpr int NBUF = KH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = (tid >> 6) & 3, kh = tid >> 8;         // cin tile, kout half
   const int li = lane & 15, g = lane >> 4;
-  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
-  const int chunk = tid % CPR, prow = tid / CPR;          // staging role
+  const int k0 = blockIdx.x * (64 * KH), c0 = blockIdx.y * 64;
+  const int chunk = tid % CPR, prow = tid / CPR;          // halo staging role
+  const int chunky = tid % (CPR * KH), prowy = tid / (CPR * KH);   // dY staging role: 16-byte chunk of the KH*64 kouts, pixel row
   const bool xform = a.in_scale != nullptr;
   // producer BN scale/shift of this workgroup's 64 input channels: kept in LDS (behind the tile buffer) and read when a
   // halo is staged -- as registers they cost 16 VGPRs through the MFMA loop, which is register-bound
@@ -72,14 +84,14 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
   unsigned hvalid = 0;                       // entry exists (hp < HP)
 #pragma unroll
   for (int i = 0; i < YL; ++i) {
-    const int p = prow + (256 / CPR) * i;
+    const int p = prowy + YROWS * i;
     const int ni = p / (TH * TW), rem = p - ni * (TH * TW);
     const int ph = rem / TW, pw = rem - ph * TW;
     rel_y[i] = (ni * a.H + ph) * a.W + pw;
   }
 #pragma unroll
   for (int i = 0; i < HL; ++i) {
-    const int hp = prow + (256 / CPR) * i;
+    const int hp = prow + HROWS * i;
     rel_h[i] = 0;
     if (hp < HP) {
       const int ni = hp / (HH * HWD), rem = hp - ni * (HH * HWD);
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
       edge |= (unsigned long long)((hr == 0) | ((hr == HH - 1) << 1) | ((hc == 0) << 2) | ((hc == HWD - 1) << 3)) << (4 * i);
     }
   }
-  const size_t ybase = ((size_t)k0 + chunk * EPC) * sizeof(T), xbase = ((size_t)c0 + chunk * EPC) * sizeof(T);
+  const size_t ybase = ((size_t)k0 + chunky * EPC) * sizeof(T), xbase = ((size_t)c0 + chunk * EPC) * sizeof(T);
 
   u32x4_t yreg[YL], hreg[HL];
   unsigned hin = 0;
@@ -122,10 +134,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
   // kernel's LDS cycles were bank conflicts).  The lanes are mapped so that those 8 rows are 8 CONSECUTIVE pixels of one
   // image row, and the 32-byte column group is XORed with bits 1..2 of the row index.
   auto swz = [](int row) { return (row >> 1) & 3; };
-  auto chunk_off = [&](int row) {               // byte offset of staging chunk `chunk` inside its row
-    if (!BF) return chunk * 16;
-    return (((chunk >> 1) ^ swz(row)) << 5) | ((chunk & 1) << 4);
+  auto chunk_off_of = [&](int row, int ch) {    // byte offset of 16-byte chunk `ch` inside its (128-byte, bf16) row
+    if (!BF) return ch * 16;
+    return (((ch >> 1) ^ swz(row)) << 5) | ((ch & 1) << 4);
   };
+  auto chunk_off = [&](int row) { return chunk_off_of(row, chunk); };
   auto store_lds = [&](int buf) {
     char* yb = smem + buf * BUF;
     char* hb = yb + YBUF;
@@ -136,12 +149,12 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
     }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
-      const int p = prow + (256 / CPR) * i;
-      st16(yb + p * RB + chunk_off(p), yreg[i]);
+      const int p = prowy + YROWS * i;
+      st16(yb + (chunky / CPR) * YH + p * RB + chunk_off_of(p, chunky % CPR), yreg[i]);
     }
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-      const int hp = prow + (256 / CPR) * i;
+      const int hp = prow + HROWS * i;
       if (hp >= HP) continue;
       const int hni = hp / (HH * HWD), hrem = hp - hni * (HH * HWD);
       const int hpl = (hni * HH + hrem / HWD) * PITCH + hrem % HWD;      // pitched LDS pixel index
@@ -207,7 +220,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
         bf16x8_t af[4];
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
-          const char* pa = yb + q * 32 * RB + Aoff[t4];
+          const char* pa = yb + kh * YH + q * 32 * RB + Aoff[t4];
           af[t4] = tr_pair(pa, pa + 8 * RB);
         }
 #pragma unroll
@@ -237,14 +250,21 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           const int toff = (t / 3) * PITCH + (t % 3);
-          const float bv = *reinterpret_cast<const float*>(hb + (hp0 + toff) * RB + (16 * wave + li) * 4);
+          const float bv = *reinterpret_cast<const float*>(hb + (hp0 + toff) * RB + (16 * wave + li) * 4);   // (fp32: KH == 1)
 #pragma unroll
           for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv, acc[t][t4], 0, 0, 0);
         }
       }
     }
-    if (NBUF == 1) __syncthreads();             // single buffer: everyone is done reading before it is overwritten
-    if (more) store_lds(NBUF == 2 ? buf ^ 1 : 0);
+    if (NBUF == 1) {
+      __syncthreads();                          // single buffer: everyone is done reading before it is overwritten
+      if (more) store_lds(0);
+    } else if (more) {
+      // double buffer: no barrier between this tile's MFMAs and the staging of the next one into the other buffer -- a wave
+      // that finishes early transforms and writes its share while the others still compute (staging it in the MIDDLE of
+      // the MFMA loop instead spilled 38-121 registers: the loop body sits at 252 of 256)
+      store_lds(buf ^ 1);
+    }
     __syncthreads();
     if (NBUF == 2) buf ^= 1;
   }
@@ -255,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_halo_kernel(const WgradArgs a
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int k = k0 + 16 * t4 + 4 * g + j;
+        const int k = k0 + 64 * kh + 16 * t4 + 4 * g + j;
         atomicAdd(a.dw + ((size_t)k * 9 + t) * a.C + c0 + 16 * wave + li, acc[t][t4][j]);
       }
 }
@@ -268,13 +288,13 @@ int wgrad_halo_tw(const WgradArgs& a) {
   return 0;
 }
 
-template <typename T, int TW>
+template <typename T, int TW, int KH>
 static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int NI = 128 / (8 * TW);
   constexpr int HP = NI * 10 * (TW + 2);
   const int ntiles = (a.N / NI) * (a.H / 8) * (a.W / TW);
-  const int kc = (a.K / 64) * (a.C / 64);
+  const int kc = (a.K / (64 * KH)) * (a.C / 64);
   // exactly one resident round: two workgroups per CU.  The pixel split decides how many fp32 atomics hit dW
   // (workgroups x 64x64x9): with twice as many workgroups the final atomics alone were 22 % of the kernel.
   int cus = 256;
@@ -282,29 +302,32 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  int splits = cdiv(2 * cus, kc);
+  int splits = cdiv((KH == 1 ? 2 : 1) * cus, kc);        // KH == 2: one 8-wave workgroup per CU
   const int max_splits = cdiv(ntiles, 16);                // at least 16 tiles per workgroup: below that the fp32 atomics of its 64x64x9 block outweigh the parallelism (RSP N=128: +4 % step)
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const int tps = cdiv(ntiles, splits);
   splits = cdiv(ntiles, tps);
   const int pitch = BF ? (TW == 16 ? 24 : 16) : TW + 2;
-  const size_t lds = (size_t)(128 + NI * 10 * pitch) * 64 * sizeof(T) + 512;
+  const size_t lds = (size_t)KH * (128 * KH + NI * 10 * pitch) * 64 * sizeof(T) + 512;     // NBUF = KH buffers of (KH dY halves + halo)
   (void)HP;
-  auto kern = wgrad3x3_halo_kernel<T, TW>;
+  auto kern = wgrad3x3_halo_kernel<T, TW, KH>;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, KH == 1 ? 96 * 1024 : 160 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.K / 64, a.C / 64, splits), dim3(256), lds, st, a, tps, ntiles);
+  hipLaunchKernelGGL(kern, dim3(a.K / (64 * KH), a.C / 64, splits), dim3(256 * KH), lds, st, a, tps, ntiles);
   return hipGetLastError();
 }
 
 hipError_t launch_wgrad_halo(int dtype, const WgradArgs& a, int tw, hipStream_t st) {
-  if (dtype == DT_BF16) return tw == 16 ? launch_wh<bf16_t, 16>(a, st) : launch_wh<bf16_t, 8>(a, st);
-  return tw == 16 ? launch_wh<float, 16>(a, st) : launch_wh<float, 8>(a, st);
+  if (dtype == DT_BF16) {
+    if (a.K % 128 == 0) return tw == 16 ? launch_wh<bf16_t, 16, 2>(a, st) : launch_wh<bf16_t, 8, 2>(a, st);
+    return tw == 16 ? launch_wh<bf16_t, 16, 1>(a, st) : launch_wh<bf16_t, 8, 1>(a, st);
+  }
+  return tw == 16 ? launch_wh<float, 16, 1>(a, st) : launch_wh<float, 8, 1>(a, st);
 }
 
 }  // namespace sslcr
