@@ -11,8 +11,10 @@ __device__ __forceinline__ void mma(const u32x4_t& a, const u32x4_t& b, f32x4_t&
 }
 // MODE 0: reads(next) ; fence ; mfmas(cur)      MODE 1: interleaved by sched_group_barrier      MODE 2: mode 0 + setprio
 // MODE 3: no LDS reads at all (MFMA ceiling)     MODE 4: reads only
-template <int WAVES, int TK, int TP, int MODE>
-__global__ __launch_bounds__(WAVES * 64, 2) void loop_kernel(float* out, int iters) {
+// NV > 0: NV extra independent VALU fmas per step on a separate register bank (stand-in for a deferred epilogue / halo transform):
+//   MODE 0 -> after the step's MFMAs in program order ; MODE 1 -> spread between the MFMAs by sched_group_barrier
+template <int WAVES, int TK, int TP, int MODE, int NV = 0, int MINW = 2>
+__global__ __launch_bounds__(WAVES * 64, MINW) void loop_kernel(float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, li = lane & 15;
@@ -28,6 +30,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void loop_kernel(float* out, int ite
   }
   f32x4_t acc[TK][TP];
   for (int t = 0; t < TK; ++t) for (int p = 0; p < TP; ++p) acc[t][p] = f32x4_t{0, 0, 0, 0};
+  float ev[32];
+  for (int e = 0; e < 32; ++e) ev[e] = 1.f + 0.001f * (tid + e);
   u32x4_t A[2][TK], B[2][TP];
   auto frags = [&](int buf, int step) {
     const int kk = step & 1, s = (step >> 1) % 3;
@@ -56,6 +60,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void loop_kernel(float* out, int ite
         for (int p = 0; p < TP; ++p) asm volatile("" ::"v"(B[i & 1][p]));
       }
       if (MODE == 2) __builtin_amdgcn_s_setprio(0);
+      if (NV > 0) {
+#pragma unroll
+        for (int e = 0; e < NV; ++e) ev[e & 31] = fmaf(ev[e & 31], 1.0001f, 0.5f);
+      }
+      if (MODE == 1 && NV > 0) {
+#pragma unroll
+        for (int q = 0; q < TK + TP; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, TK * TP / (TK + TP), 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, NV / (TK + TP), 0);
+        }
+      } else
       if (MODE == 1) {
 #pragma unroll
         for (int q = 0; q < TK + TP; ++q) {
@@ -67,13 +83,14 @@ __global__ __launch_bounds__(WAVES * 64, 2) void loop_kernel(float* out, int ite
     }
   }
   float s = 0;
+  for (int e = 0; e < 32; ++e) s += ev[e];
   for (int t = 0; t < TK; ++t) for (int p = 0; p < TP; ++p) s += acc[t][p][0] + acc[t][p][1] + acc[t][p][2] + acc[t][p][3];
   out[blockIdx.x * WAVES * 64 + tid] = s;
 }
-template <int WAVES, int TK, int TP, int MODE>
+template <int WAVES, int TK, int TP, int MODE, int NV = 0, int MINW = 2>
 void run(const char* name, int grid_mul) {
   float* out; hipMalloc(&out, 4 << 20);
-  auto k = loop_kernel<WAVES, TK, TP, MODE>;
+  auto k = loop_kernel<WAVES, TK, TP, MODE, NV, MINW>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   const int iters = 2000, grid = 256 * grid_mul;
   const size_t lds = grid_mul == 1 ? 150 * 1024 : 75 * 1024;
@@ -99,6 +116,15 @@ int main() {
   run<4, 8, 4, 0>("4w 8x4 (1 wave/SIMD) mode0", 1);
   run<4, 8, 4, 1>("4w 8x4 interleaved", 1);
   run<4, 8, 4, 3>("4w 8x4 MFMA only", 1);
+  run<8, 4, 4, 0, 64>("8w 4x4 mode0 + 64 VALU/step after", 1);
+  run<8, 4, 4, 1, 64>("8w 4x4 interleaved + 64 VALU/step spread", 1);
+  run<8, 4, 4, 0, 128>("8w 4x4 mode0 + 128 VALU/step after", 1);
+  run<8, 4, 4, 1, 128>("8w 4x4 interleaved + 128 VALU/step spread", 1);
+  run<4, 8, 4, 0, 0, 1>("4w 8x4 512-reg budget mode0", 1);
+  run<4, 8, 4, 1, 0, 1>("4w 8x4 512-reg budget interleaved", 1);
+  run<4, 8, 4, 0, 128, 1>("4w 8x4 512-reg + 128 VALU/step after", 1);
+  run<4, 8, 4, 1, 132, 1>("4w 8x4 512-reg + 132 VALU/step spread", 1);
+  run<4, 8, 4, 1, 264, 1>("4w 8x4 512-reg + 264 VALU/step spread", 1);
   run<8, 2, 4, 0>("8w 2x4 mode0", 1);
   run<8, 2, 4, 1>("8w 2x4 interleaved", 1);
   return 0;
