@@ -378,35 +378,41 @@ Dims make_dims(int H, int W) {
   return d;
 }
 
-int alloc_pass(sslcr_net* n, PassState& ps, int N, int H, int W) {
+// Saved activations of ALL passes (1, or the 3 TripletNet branches) in one buffer, laid out [tensor][pass][...]: a tensor of
+// pass p+1 follows the same tensor of pass p, so a weight-gradient launch can take the branches as one 3N-image batch
+// (dW is linear in the pixels; at N=128 per branch the per-launch fp32 atomics into dW dominated the RSP step).
+int alloc_passes(sslcr_net* n, int npass, int N, int H, int W) {
   const size_t es = n->ctx->esz();
   const Dims d = make_dims(H, W);
   Carver c;
-  const size_t o_raw0 = c.take((size_t)N * d.oh0 * d.ow0 * 64 * es);
-  const size_t o_pool = c.take((size_t)N * d.ph * d.pw * 64 * es);
-  const size_t o_arg = c.take((size_t)N * d.ph * d.pw * 64);
-  size_t o_blk[8][4];
+  auto take = [&](size_t per_pass) { return c.take(per_pass * npass); };   // (every per-pass size is a multiple of 128 bytes)
+  const size_t s_raw0 = (size_t)N * d.oh0 * d.ow0 * 64 * es, s_pool = (size_t)N * d.ph * d.pw * 64 * es, s_arg = (size_t)N * d.ph * d.pw * 64;
+  const size_t o_raw0 = take(s_raw0), o_pool = take(s_pool), o_arg = take(s_arg);
+  size_t o_blk[8][4], s_blk[8];
   for (int i = 0; i < 8; ++i) {
-    const size_t sz = (size_t)N * d.lh[i] * d.lw[i] * kBlockCfg[i][1] * es;
-    for (int j = 0; j < 4; ++j) o_blk[i][j] = (j == 2 && !n->blocks[i].has_ds) ? 0 : c.take(sz);
+    s_blk[i] = (size_t)N * d.lh[i] * d.lw[i] * kBlockCfg[i][1] * es;
+    for (int j = 0; j < 4; ++j) o_blk[i][j] = (j == 2 && !n->blocks[i].has_ds) ? 0 : take(s_blk[i]);
   }
-  const size_t o_bn = c.take(20 * 4 * 512 * sizeof(float));
-  const size_t o_E = c.take((size_t)N * 512 * sizeof(float));
-  TRYI(ps.mem.ensure(c.off));
-  char* b = (char*)ps.mem.p;
-  ps.raw0 = b + o_raw0; ps.pooled = b + o_pool; ps.argmax = (uint8_t*)(b + o_arg);
-  for (int i = 0; i < 8; ++i) {
-    ps.blk[i].raw1 = b + o_blk[i][0]; ps.blk[i].raw2 = b + o_blk[i][1];
-    ps.blk[i].rawd = n->blocks[i].has_ds ? b + o_blk[i][2] : nullptr;
-    ps.blk[i].y = b + o_blk[i][3];
+  const size_t s_bn = 20 * 4 * 512 * sizeof(float), s_E = (size_t)N * 512 * sizeof(float);
+  const size_t o_bn = take(s_bn), o_E = take(s_E);
+  TRYI(n->pass[0].mem.ensure(c.off));
+  char* b = (char*)n->pass[0].mem.p;
+  for (int p = 0; p < npass; ++p) {
+    PassState& ps = n->pass[p];
+    ps.raw0 = b + o_raw0 + p * s_raw0; ps.pooled = b + o_pool + p * s_pool; ps.argmax = (uint8_t*)(b + o_arg + p * s_arg);
+    for (int i = 0; i < 8; ++i) {
+      ps.blk[i].raw1 = b + o_blk[i][0] + p * s_blk[i]; ps.blk[i].raw2 = b + o_blk[i][1] + p * s_blk[i];
+      ps.blk[i].rawd = n->blocks[i].has_ds ? b + o_blk[i][2] + p * s_blk[i] : nullptr;
+      ps.blk[i].y = b + o_blk[i][3] + p * s_blk[i];
+    }
+    float* f = (float*)(b + o_bn + p * s_bn);
+    for (int i = 0; i < 20; ++i) {
+      ps.bn[i] = BnSaved{f, f + 512, f + 1024, f + 1536};
+      f += 2048;
+    }
+    ps.E = (float*)(b + o_E + p * s_E);
+    ps.N = N; ps.H = H; ps.W = W;
   }
-  float* f = (float*)(b + o_bn);
-  for (int i = 0; i < 20; ++i) {
-    ps.bn[i] = BnSaved{f, f + 512, f + 1024, f + 1536};
-    f += 2048;
-  }
-  ps.E = (float*)(b + o_E);
-  ps.N = N; ps.H = H; ps.W = W;
   return 0;
 }
 
@@ -414,7 +420,7 @@ int alloc_pass(sslcr_net* n, PassState& ps, int N, int H, int W) {
 int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f32, int N, int H, int W, int replay, hipStream_t st) {
   sslcr_ctx* c = n->ctx;
   const int dt = c->dtype;
-  if (ps.N != N || ps.H != H || ps.W != W || !ps.mem.p) TRYI(alloc_pass(n, ps, N, H, W));
+  if (n->pass[0].N != N || n->pass[0].H != H || n->pass[0].W != W || !n->pass[0].mem.p) TRYI(alloc_passes(n, n->triplet ? 3 : 1, N, H, W));
   ps.x = x; ps.in_f32 = in_f32;
   ps.x2 = n->split_x2; ps.n_split = n->split_x2 ? n->split_n : 0;
   const Dims d = make_dims(H, W);
@@ -695,116 +701,137 @@ int lowest_trainable(const sslcr_net* n) {
   return 60;
 }
 
-int backbone_backward(sslcr_net* n, PassState& ps, const float* dE, bool last_pass, hipStream_t st) {
+// Backward of the backbone for all passes, walked LAYER-major: per block the BatchNorm backward / dgrad chain runs pass by
+// pass (the reference's BatchNorm statistics are per branch), the weight gradients of conv1 and of the projection run ONCE
+// over the branches' contiguous (x, dy) tensors (alloc_passes; scratch buffers of one kind are contiguous across passes too).
+int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
   sslcr_ctx* c = n->ctx;
   const int dt = c->dtype;
   const size_t es = c->esz();
-  const int N = ps.N;
-  const Dims d = make_dims(ps.H, ps.W);
+  PassState* P = n->pass;
+  const int N = P[0].N;
+  const Dims d = make_dims(P[0].H, P[0].W);
   const int low = lowest_trainable(n);
   if (low >= 60) return 0;
-  // transient buffers: bufA = {dOut, G, dRaw2, dAct1} ; bufB = {dRaw1, dXin, dRawD, -}; each slot one layer1-sized unit;
-  // the stem uses all of A (g0) then all of B (dRaw0)
+  // transient buffers, one layer1-sized unit each, laid out [kind][pass]: dOut, G, dRaw2, dAct1, dRaw1, dXin, dRawD; behind
+  // them one stem-sized region for dRaw0 (used pass by pass)
   const size_t unit = (((size_t)N * d.ph * d.pw * 64 * es) + 255) & ~(size_t)255;
-  const size_t stem_sz = (size_t)N * d.oh0 * d.ow0 * 64 * es;
-  const size_t half = (4 * unit > stem_sz) ? 4 * unit : ((stem_sz + 255) & ~(size_t)255);
-  TRYI(c->scratch.ensure(2 * half));
-  char* A = (char*)c->scratch.p;
-  char* Bf = A + half;
-  char *dOut = A, *G = A + unit, *dRaw2 = A + 2 * unit, *dAct1 = A + 3 * unit;
-  char *dRaw1 = Bf, *dXin = Bf + unit, *dRawD = Bf + 2 * unit;
+  const size_t stem_sz = (((size_t)N * d.oh0 * d.ow0 * 64 * es) + 255) & ~(size_t)255;
+  TRYI(c->scratch.ensure(7 * npass * unit + stem_sz));
+  char* S = (char*)c->scratch.p;
+  // pass p of a kind sits p * (tensor bytes of the current layer) behind pass 0: contiguous for the batched weight gradients
+  auto buf = [&](int kind, int p, size_t bytes) { return S + (size_t)kind * npass * unit + (size_t)p * bytes; };
+  int kOut = 0, kXin = 5;
+  const int kG = 1, kRaw2 = 2, kAct1 = 3, kRaw1 = 4, kRawD = 6;
+  char* dRaw0 = S + (size_t)7 * npass * unit;
 
   size_t hi_pending = n->goff[60];
   int bucket = 1;
-  TRY(launch_avgpool_bwd(dt, dE, dOut, N, d.lh[7] * d.lw[7], 512, st));
+  for (int p = 0; p < npass; ++p)
+    TRY(launch_avgpool_bwd(dt, n->dE[p], buf(kOut, p, (size_t)N * d.lh[7] * d.lw[7] * 512 * es), N, d.lh[7] * d.lw[7], 512, st));
   for (int i = 7; i >= 0; --i) {
     BlockL& B = n->blocks[i];
     const int oh = d.lh[i], ow = d.lw[i];
     const int xh = i == 0 ? d.ph : d.lh[i - 1], xw = i == 0 ? d.pw : d.lw[i - 1];
-    const char* X = i == 0 ? ps.pooled : ps.blk[i - 1].y;
     const size_t opix = (size_t)N * oh * ow;
     const bool need_dx = low < B.pstart;          // something upstream of this block is trainable
-    // bn2 (+ relu mask from the block output): its REDUCE pass leaves G = dOut * (y > 0) in scratch; the apply pass, the
-    // projection shortcut's BatchNorm and the identity path all read G instead of (dOut, y) again
-    TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, nullptr, 1));
-    if (B.has_ds)
-      TRYI(bn_backward(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st));
-    TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
-    float* b1_rows = nullptr;
-    int b1_nrows = 0;
-    {
-      ConvArgs a = conv_args(B.c2, dRaw2, B.c2.w_dg, dAct1, N, oh, ow);      // dgrad 3x3/1: gather over dRaw2 [.,K] with [C][R][S][K]
-      a.C = B.c2.cout; a.K = B.c2.cin; a.transposed = 0; a.PH = oh; a.PW = ow; a.OH = oh; a.OW = ow;   // flipped pack
-      // where the 16x16-tile kernel serves this dgrad it also applies bn1's ReLU mask and leaves bn1's two backward sums
-      // in its stats rows: bn1's reduce pass over (dAct1, raw1) is not run
-      ConvArgs m = a;
-      const BnSaved& s1 = ps.bn[B.b1.bidx];
-      m.mask_x = ps.blk[i].raw1; m.mask_scale = s1.scale; m.mask_shift = s1.shift; m.mask_mean = s1.mean;
-      if (conv_h16_ok(dt, m)) {
-        TRYI(ensure_partials(c, m, &b1_rows, &b1_nrows));
-        m.stats = b1_rows;
-        a = m;
-      }
-      TRY(prof_conv(c, dt,a, st));
-    }
-    TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, b1_rows ? 0 : 1, dRaw1, nullptr, opix, (double)opix, st,
-                     nullptr, 0, b1_rows, b1_nrows));
-    TRYI(wgrad_call(n, B.c1, X, dRaw1, nullptr, N, xh, xw, oh, ow, st));
-    if (B.has_ds) TRYI(wgrad_call(n, B.ds, X, dRawD, nullptr, N, xh, xw, oh, ow, st));
-    if (need_dx) {
-      ConvArgs a = conv_args(B.c1, dRaw1, B.c1.w_dg, dXin, N, oh, ow);
-      a.C = B.c1.cout; a.K = B.c1.cin; a.transposed = (B.c1.stride == 1) ? 0 : 1; a.PH = xh; a.PW = xw; a.OH = xh; a.OW = xw;
-      if (!B.has_ds) a.residual = G;
-      if (B.c1.stride == 1) {
+    const size_t so = opix * B.c2.cout * es, si = (size_t)N * xh * xw * B.c1.cin * es;     // bytes of this block's output / input per pass
+    for (int p = 0; p < npass; ++p) {
+      PassState& ps = P[p];
+      char *dOut = buf(kOut, p, so), *G = buf(kG, p, so), *dRaw2 = buf(kRaw2, p, so), *dAct1 = buf(kAct1, p, so), *dRaw1 = buf(kRaw1, p, so),
+           *dRawD = buf(kRawD, p, so);
+      // bn2 (+ relu mask from the block output): its REDUCE pass leaves G = dOut * (y > 0) in scratch; the apply pass, the
+      // projection shortcut's BatchNorm and the identity path all read G instead of (dOut, y) again
+      TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, nullptr, 1));
+      if (B.has_ds)
+        TRYI(bn_backward(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st));
+      // conv2's wgrad applies bn1 + ReLU of THIS pass to its input on the fly: per pass
+      TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
+      float* b1_rows = nullptr;
+      int b1_nrows = 0;
+      {
+        ConvArgs a = conv_args(B.c2, dRaw2, B.c2.w_dg, dAct1, N, oh, ow);      // dgrad 3x3/1: gather over dRaw2 [.,K] with [C][R][S][K]
+        a.C = B.c2.cout; a.K = B.c2.cin; a.transposed = 0; a.PH = oh; a.PW = ow; a.OH = oh; a.OW = ow;   // flipped pack
+        // where the 16x16-tile kernel serves this dgrad it also applies bn1's ReLU mask and leaves bn1's two backward sums
+        // in its stats rows: bn1's reduce pass over (dAct1, raw1) is not run
+        ConvArgs m = a;
+        const BnSaved& s1 = ps.bn[B.b1.bidx];
+        m.mask_x = ps.blk[i].raw1; m.mask_scale = s1.scale; m.mask_shift = s1.shift; m.mask_mean = s1.mean;
+        if (conv_h16_ok(dt, m)) {
+          TRYI(ensure_partials(c, m, &b1_rows, &b1_nrows));
+          m.stats = b1_rows;
+          a = m;
+        }
         TRY(prof_conv(c, dt,a, st));
-      } else {
-        // stride-2 dgrad: each input-pixel parity class (ph%2, pw%2) only sees the taps with (p + pad - r) even --
-        // 1 + 2 + 2 + 4 = 9 taps over four launches instead of 36 tap visits with three quarters zero-gathered
-        for (int par = 0; par < 4; ++par) {
-          ConvArgs q = a;
-          const int ph_ = par >> 1, pw_ = par & 1;
-          q.pix_mul = 2; q.pix_off_h = ph_; q.pix_off_w = pw_;
-          q.PH = (xh - ph_ + 1) / 2; q.PW = (xw - pw_ + 1) / 2;
-          if (q.PH <= 0 || q.PW <= 0) continue;
-          unsigned m = 0;
-          for (int r = 0; r < 3; ++r)
-            for (int s2 = 0; s2 < 3; ++s2)
-              if (((ph_ + 1 - r) & 1) == 0 && ((pw_ + 1 - s2) & 1) == 0) m |= 1u << (r * 3 + s2);
-          q.tap_mask = m;
-          TRY(prof_conv(c, dt,q, st));
+      }
+      TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, b1_rows ? 0 : 1, dRaw1, nullptr, opix, (double)opix, st,
+                       nullptr, 0, b1_rows, b1_nrows));
+    }
+    // conv1 / projection weight gradients: one launch over the npass * N images (x and dy contiguous across passes)
+    {
+      const char* X0 = i == 0 ? P[0].pooled : P[0].blk[i - 1].y;
+      TRYI(wgrad_call(n, B.c1, X0, buf(kRaw1, 0, so), nullptr, N * npass, xh, xw, oh, ow, st));
+      if (B.has_ds) TRYI(wgrad_call(n, B.ds, X0, buf(kRawD, 0, so), nullptr, N * npass, xh, xw, oh, ow, st));
+    }
+    if (need_dx) {
+      for (int p = 0; p < npass; ++p) {
+        char *G = buf(kG, p, so), *dRaw1 = buf(kRaw1, p, so), *dXin = buf(kXin, p, si), *dRawD = buf(kRawD, p, so);
+        ConvArgs a = conv_args(B.c1, dRaw1, B.c1.w_dg, dXin, N, oh, ow);
+        a.C = B.c1.cout; a.K = B.c1.cin; a.transposed = (B.c1.stride == 1) ? 0 : 1; a.PH = xh; a.PW = xw; a.OH = xh; a.OW = xw;
+        if (!B.has_ds) a.residual = G;
+        if (B.c1.stride == 1) {
+          TRY(prof_conv(c, dt,a, st));
+        } else {
+          // stride-2 dgrad: each input-pixel parity class (ph%2, pw%2) only sees the taps with (p + pad - r) even --
+          // 1 + 2 + 2 + 4 = 9 taps over four launches instead of 36 tap visits with three quarters zero-gathered
+          for (int par = 0; par < 4; ++par) {
+            ConvArgs q = a;
+            const int ph_ = par >> 1, pw_ = par & 1;
+            q.pix_mul = 2; q.pix_off_h = ph_; q.pix_off_w = pw_;
+            q.PH = (xh - ph_ + 1) / 2; q.PW = (xw - pw_ + 1) / 2;
+            if (q.PH <= 0 || q.PW <= 0) continue;
+            unsigned m = 0;
+            for (int r = 0; r < 3; ++r)
+              for (int s2 = 0; s2 < 3; ++s2)
+                if (((ph_ + 1 - r) & 1) == 0 && ((pw_ + 1 - s2) & 1) == 0) m |= 1u << (r * 3 + s2);
+            q.tap_mask = m;
+            TRY(prof_conv(c, dt,q, st));
+          }
+        }
+        if (B.has_ds) {       // 1x1/2 projection: scatter-accumulate into the even positions of dXin
+          ConvArgs s = conv_args(B.ds, dRawD, B.ds.w_dg, dXin, N, oh, ow);
+          s.C = B.ds.cout; s.K = B.ds.cin; s.stride = 1; s.pad = 0; s.PH = oh; s.PW = ow; s.OH = xh; s.OW = xw; s.osh = B.ds.stride;
+          s.accumulate = 1;
+          TRY(prof_conv(c, dt,s, st));
         }
       }
-      if (B.has_ds) {       // 1x1/2 projection: scatter-accumulate into the even positions of dXin
-        ConvArgs s = conv_args(B.ds, dRawD, B.ds.w_dg, dXin, N, oh, ow);
-        s.C = B.ds.cout; s.K = B.ds.cin; s.stride = 1; s.pad = 0; s.PH = oh; s.PW = ow; s.OH = xh; s.OW = xw; s.osh = B.ds.stride;
-        s.accumulate = 1;
-        TRY(prof_conv(c, dt,s, st));
-      }
-      char* t = dOut; dOut = dXin; dXin = t;        // ping-pong: this block's input gradient is the next dOut
+      const int t = kOut; kOut = kXin; kXin = t;      // ping-pong: this block's input gradient is the next dOut
     }
-    if (last_pass && (i == 6 || i == 4 || i == 2)) {   // layer4 / layer3 / layer2 gradients are final: reduce them under the rest of backward
+    if (i == 6 || i == 4 || i == 2) {   // layer4 / layer3 / layer2 gradients are final: reduce them under the rest of backward
       TRYI(launch_bucket_allreduce(n, bucket++, n->goff[B.pstart], hi_pending, st));
       hi_pending = n->goff[B.pstart];
     }
     if (!need_dx) break;
   }
   if (low < 3) {
-    // stem: maxpool+relu backward -> bn0 backward -> conv1 wgrad (no dgrad: the input is data)
-    // dOut (= dP, the pooled gradient) sits in one half of the scratch; dRaw0 goes to the other half.  The max-pool + ReLU
-    // backward is folded into both BatchNorm-backward passes (the un-pooled gradient is never written out).
-    char* dRaw0 = (dOut >= Bf) ? A : Bf;
-    PoolSrc pool{dOut, ps.argmax, d.oh0, d.ow0, d.ph, d.pw, ps.pooled};
-    const size_t spix = (size_t)N * d.oh0 * d.ow0;
-    TRYI(bn_backward(n, n->bn0, ps.bn[0], nullptr, ps.raw0, nullptr, 1, dRaw0, nullptr, spix, (double)spix, st, &pool));
-    if (n->rg[0]) {
-      StemWgradArgs w;
-      memset(&w, 0, sizeof(w));
-      w.x = ps.x; w.x2 = ps.x2; w.n_split = ps.n_split; w.dy = dRaw0; w.dw = (float*)n->grads.p + n->goff[0];
-      w.N = N; w.H = ps.H; w.W = ps.W; w.OH = d.oh0; w.OW = d.ow0; w.in_f32 = ps.in_f32;
-      TRY(launch_stem_wgrad(dt, w, st));
+    // stem: maxpool+relu backward -> bn0 backward -> conv1 wgrad (no dgrad: the input is data), pass by pass.
+    // dOut (= dP, the pooled gradient) of pass p sits in its scratch unit, dRaw0 in the stem-sized region behind the units.  The
+    // max-pool + ReLU backward is folded into both BatchNorm-backward passes (the un-pooled gradient is never written out).
+    for (int p = 0; p < npass; ++p) {
+      PassState& ps = P[p];
+      PoolSrc pool{buf(kOut, p, (size_t)N * d.ph * d.pw * 64 * es), ps.argmax, d.oh0, d.ow0, d.ph, d.pw, ps.pooled};
+      const size_t spix = (size_t)N * d.oh0 * d.ow0;
+      TRYI(bn_backward(n, n->bn0, ps.bn[0], nullptr, ps.raw0, nullptr, 1, dRaw0, nullptr, spix, (double)spix, st, &pool));
+      if (n->rg[0]) {
+        StemWgradArgs w;
+        memset(&w, 0, sizeof(w));
+        w.x = ps.x; w.x2 = ps.x2; w.n_split = ps.n_split; w.dy = dRaw0; w.dw = (float*)n->grads.p + n->goff[0];
+        w.N = N; w.H = ps.H; w.W = ps.W; w.OH = d.oh0; w.OW = d.ow0; w.in_f32 = ps.in_f32;
+        TRY(launch_stem_wgrad(dt, w, st));
+      }
     }
   }
-  if (last_pass) TRYI(launch_bucket_allreduce(n, bucket, 0, hi_pending, st));
+  TRYI(launch_bucket_allreduce(n, bucket, 0, hi_pending, st));
   return 0;
 }
 
@@ -840,7 +867,7 @@ int net_backward(sslcr_net* n, const float* dlogits, hipStream_t st) {
   TRYI(heads_backward(n, dlogits, npass, N, bb, st));
   TRYI(launch_bucket_allreduce(n, 0, n->goff[60], n->goff[n->nparams], st));
   if (bb) {
-    for (int i = npass - 1; i >= 0; --i) TRYI(backbone_backward(n, n->pass[i], n->dE[i], i == 0, st));
+    TRYI(backbone_backward(n, npass, st));
   }
   if (c->comm_g) {
     TRY(hipEventRecord(c->ev_done, c->comm_stream));
