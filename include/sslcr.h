@@ -67,6 +67,9 @@ typedef struct sslcr_wgrad_desc {
   const float* in_shift;
   int in_relu;
   int N, H, W, C, K, R, S, stride, pad, OH, OW;
+  int seg_images;         /* optional (> 0, divides N; 3x3 stride-1 halo kernel shapes only): the batch is N / seg_images segments   */
+  int seg_stride;         /* with their own producer BatchNorm -- segment s uses in_scale + s*seg_stride, in_shift + s*seg_stride    */
+                          /* (the TripletNet branches as one batch: dW is linear in the pixels, their statistics are per branch)    */
 } sslcr_wgrad_desc;
 int sslcr_conv2d_wgrad(int dtype, const sslcr_wgrad_desc* d, void* stream);
 

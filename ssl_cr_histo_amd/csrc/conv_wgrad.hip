@@ -220,6 +220,7 @@ const char* wgrad_kernel_name(int dtype, const WgradArgs& a) {
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st) {
   const int tw = wgrad_halo_tw(a);
   if (tw) return launch_wgrad_halo(dtype, a, tw, st);
+  if (a.seg_images > 0 && a.seg_images < a.N) return hipErrorInvalidValue;      // per-segment prologue: halo kernel only
   const bool three = a.R == 3;
   if (dtype == DT_BF16) return three ? launch_w<bf16_t, 9>(a, st) : launch_w<bf16_t, 1>(a, st);
   return three ? launch_w<float, 9>(a, st) : launch_w<float, 1>(a, st);

@@ -673,13 +673,16 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
   return 0;
 }
 
-int wgrad_call(sslcr_net* n, const ConvL& L, const void* x, const void* dy, const BnSaved* pro, int N, int H, int W, int OH, int OW, hipStream_t st) {
+// seg_images > 0: the N images are N / seg_images segments (TripletNet branches) whose producer BatchNorms sit seg_stride floats apart
+int wgrad_call(sslcr_net* n, const ConvL& L, const void* x, const void* dy, const BnSaved* pro, int N, int H, int W, int OH, int OW, hipStream_t st,
+               int seg_images = 0, int seg_stride = 0) {
   if (!n->rg[L.pidx]) return 0;
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.dy = dy; a.dw = (float*)n->grads.p + n->goff[L.pidx];
   if (pro) { a.in_scale = pro->scale; a.in_shift = pro->shift; a.in_relu = 1; }
   a.N = N; a.H = H; a.W = W; a.C = L.cin; a.K = L.cout; a.R = L.k; a.S = L.k; a.stride = L.stride; a.pad = L.pad; a.OH = OH; a.OW = OW;
+  a.seg_images = seg_images; a.seg_stride = seg_stride;
   TRY(prof_wgrad(n->ctx, n->ctx->dtype, a, st));
   return 0;
 }
@@ -736,6 +739,15 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
     const size_t opix = (size_t)N * oh * ow;
     const bool need_dx = low < B.pstart;          // something upstream of this block is trainable
     const size_t so = opix * B.c2.cout * es, si = (size_t)N * xh * xw * B.c1.cin * es;     // bytes of this block's output / input per pass
+    // conv2's weight gradient applies bn1 + ReLU of its pass to the input on the fly: the halo kernel takes the passes as
+    // segments with their own (scale, shift); other shapes go pass by pass
+    bool c2_batched = false;
+    if (npass > 1) {
+      WgradArgs q;
+      memset(&q, 0, sizeof(q));
+      q.N = N * npass; q.H = oh; q.W = ow; q.C = B.c2.cin; q.K = B.c2.cout; q.R = 3; q.S = 3; q.stride = 1; q.pad = 1; q.OH = oh; q.OW = ow;
+      c2_batched = wgrad_halo_tw(q) != 0 && (wgrad_halo_tw(q) == 16 || N % 2 == 0);
+    }
     for (int p = 0; p < npass; ++p) {
       PassState& ps = P[p];
       char *dOut = buf(kOut, p, so), *G = buf(kG, p, so), *dRaw2 = buf(kRaw2, p, so), *dAct1 = buf(kAct1, p, so), *dRaw1 = buf(kRaw1, p, so),
@@ -745,8 +757,7 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, nullptr, 1));
       if (B.has_ds)
         TRYI(bn_backward(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st));
-      // conv2's wgrad applies bn1 + ReLU of THIS pass to its input on the fly: per pass
-      TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
+      if (!c2_batched) TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
       float* b1_rows = nullptr;
       int b1_nrows = 0;
       {
@@ -767,16 +778,21 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, b1_rows ? 0 : 1, dRaw1, nullptr, opix, (double)opix, st,
                        nullptr, 0, b1_rows, b1_nrows));
     }
-    // conv1 / projection weight gradients: one launch over the npass * N images (x and dy contiguous across passes)
+    // weight gradients: one launch over the npass * N images (x and dy contiguous across passes)
+    if (c2_batched)
+      TRYI(wgrad_call(n, B.c2, P[0].blk[i].raw1, buf(kRaw2, 0, so), &P[0].bn[B.b1.bidx], N * npass, oh, ow, oh, ow, st, N,
+                      (int)(P[1].bn[B.b1.bidx].scale - P[0].bn[B.b1.bidx].scale)));
     {
       const char* X0 = i == 0 ? P[0].pooled : P[0].blk[i - 1].y;
       TRYI(wgrad_call(n, B.c1, X0, buf(kRaw1, 0, so), nullptr, N * npass, xh, xw, oh, ow, st));
       if (B.has_ds) TRYI(wgrad_call(n, B.ds, X0, buf(kRawD, 0, so), nullptr, N * npass, xh, xw, oh, ow, st));
     }
     if (need_dx) {
-      for (int p = 0; p < npass; ++p) {
-        char *G = buf(kG, p, so), *dRaw1 = buf(kRaw1, p, so), *dXin = buf(kXin, p, si), *dRawD = buf(kRawD, p, so);
-        ConvArgs a = conv_args(B.c1, dRaw1, B.c1.w_dg, dXin, N, oh, ow);
+      {
+        // conv1's dgrad (and the projection's) has no BatchNorm in it and is independent per image: one launch over all passes
+        const int NB = N * npass;
+        char *G = buf(kG, 0, so), *dRaw1 = buf(kRaw1, 0, so), *dXin = buf(kXin, 0, si), *dRawD = buf(kRawD, 0, so);
+        ConvArgs a = conv_args(B.c1, dRaw1, B.c1.w_dg, dXin, NB, oh, ow);
         a.C = B.c1.cout; a.K = B.c1.cin; a.transposed = (B.c1.stride == 1) ? 0 : 1; a.PH = xh; a.PW = xw; a.OH = xh; a.OW = xw;
         if (!B.has_ds) a.residual = G;
         if (B.c1.stride == 1) {
@@ -799,7 +815,7 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
           }
         }
         if (B.has_ds) {       // 1x1/2 projection: scatter-accumulate into the even positions of dXin
-          ConvArgs s = conv_args(B.ds, dRawD, B.ds.w_dg, dXin, N, oh, ow);
+          ConvArgs s = conv_args(B.ds, dRawD, B.ds.w_dg, dXin, NB, oh, ow);
           s.C = B.ds.cout; s.K = B.ds.cin; s.stride = 1; s.pad = 0; s.PH = oh; s.PW = ow; s.OH = xh; s.OW = xw; s.osh = B.ds.stride;
           s.accumulate = 1;
           TRY(prof_conv(c, dt,s, st));

@@ -62,10 +62,13 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
   const bool xform = a.in_scale != nullptr;
   // producer BN scale/shift of this workgroup's 64 input channels: kept in LDS (behind the tile buffer) and read when a
   // halo is staged -- as registers they cost 16 VGPRs through the MFMA loop, which is register-bound
+  // (one set per segment of seg_images images when the batch carries several producer BatchNorms, see sslcr_wgrad_desc)
   float* s_aff = reinterpret_cast<float*>(smem + NBUF * BUF);
-  if (tid < 64) {
-    s_aff[tid] = xform ? a.in_scale[c0 + tid] : 1.f;
-    s_aff[64 + tid] = xform ? a.in_shift[c0 + tid] : 0.f;
+  const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
+  for (int i = tid; i < nseg * 64; i += NT) {
+    const int sg = i >> 6, ch = i & 63;
+    s_aff[sg * 128 + ch] = xform ? a.in_scale[(size_t)sg * a.seg_stride + c0 + ch] : 1.f;
+    s_aff[sg * 128 + 64 + ch] = xform ? a.in_shift[(size_t)sg * a.seg_stride + c0 + ch] : 0.f;
   }
   const int tiles_w = a.W / TW, tiles_h = a.H / TH;
   const int t_begin = blockIdx.z * tiles_per_split;
@@ -105,12 +108,14 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
 
   u32x4_t yreg[YL], hreg[HL];
   unsigned hin = 0;
+  int seg_ld = 0;                               // segment of the tile whose operands sit in yreg / hreg
   auto load_regs = [&](int tile) {
     int t = tile;
     const int tw_i = t % tiles_w; t /= tiles_w;
     const int th_i = t % tiles_h;
     const int n0 = (t / tiles_h) * NI;
     const int h0 = th_i * TH, w0 = tw_i * TW;
+    seg_ld = a.seg_images > 0 ? n0 / a.seg_images : 0;
     const int origin = (n0 * a.H + h0) * a.W + w0;                    // pixel index of the tile's (0,0)
     // which halo rings fall outside the image for this tile (uniform)
     const unsigned long long out =
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
     float r_scale[EPC], r_shift[EPC];
     if (xform) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) { r_scale[e] = s_aff[chunk * EPC + e]; r_shift[e] = s_aff[64 + chunk * EPC + e]; }
+      for (int e = 0; e < EPC; ++e) { r_scale[e] = s_aff[seg_ld * 128 + chunk * EPC + e]; r_shift[e] = s_aff[seg_ld * 128 + 64 + chunk * EPC + e]; }
     }
 #pragma unroll
     for (int i = 0; i < YL; ++i) {
@@ -309,7 +314,9 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   const int tps = cdiv(ntiles, splits);
   splits = cdiv(ntiles, tps);
   const int pitch = BF ? (TW == 16 ? 24 : 16) : TW + 2;
-  const size_t lds = (size_t)KH * (128 * KH + NI * 10 * pitch) * 64 * sizeof(T) + 512;     // NBUF = KH buffers of (KH dY halves + halo)
+  const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
+  if (nseg > 8 || (a.seg_images > 0 && (a.N % a.seg_images != 0 || a.seg_images % NI != 0))) return hipErrorInvalidValue;
+  const size_t lds = (size_t)KH * (128 * KH + NI * 10 * pitch) * 64 * sizeof(T) + 512 * nseg;     // NBUF = KH buffers of (KH dY halves + halo)
   (void)HP;
   auto kern = wgrad3x3_halo_kernel<T, TW, KH>;
   static bool attr_done = false;

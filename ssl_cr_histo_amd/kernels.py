@@ -69,14 +69,15 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
     return (y, stats) if want_stats else y
 
 
-def conv2d_wgrad(x, dy, dw, R, S, stride, pad, *, in_scale=None, in_shift=None, in_relu=False):
-    """accumulate dW [K,R,S,C] fp32 += wgrad(x NHWC, dy NHWC)."""
+def conv2d_wgrad(x, dy, dw, R, S, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, seg_images=0):
+    """accumulate dW [K,R,S,C] fp32 += wgrad(x NHWC, dy NHWC).  seg_images > 0: in_scale / in_shift are [N // seg_images, C],
+    one producer BatchNorm per segment of seg_images images."""
     _chk(x, dy, dw, in_scale, in_shift)
     N, H, W, C = x.shape
     _, OH, OW, K = dy.shape
     assert dw.shape == (K, R, S, C) and dw.dtype == torch.float32
     d = L.WgradDesc(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
-                    N, H, W, C, K, R, S, stride, pad, OH, OW)
+                    N, H, W, C, K, R, S, stride, pad, OH, OW, int(seg_images), C if seg_images else 0)
     L.check(L.lib().sslcr_conv2d_wgrad(_dt(x), d, L.stream_ptr()))
 
 

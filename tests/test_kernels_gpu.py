@@ -197,6 +197,27 @@ def test_conv_wgrad(case, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", [(6, 16, 16, 64, 64, 2), (12, 16, 32, 128, 128, 4), (6, 8, 8, 256, 256, 2), (9, 32, 32, 64, 128, 3)])
+def test_conv_wgrad_segments(case, dtype):
+    """sslcr_wgrad_desc.seg_images: one launch over several segments (TripletNet branches) with their own producer BatchNorm
+    == the sum of the per-segment weight gradients."""
+    K = _k()
+    N, H, W, C, Ko, seg = case
+    nseg = N // seg
+    x = q(rnd(25, (N, H, W, C)), dtype)
+    dy = q(rnd(26, (N, H, W, Ko)), dtype)
+    sc, sh = rnd(27, (nseg, C)).abs() + 0.5, rnd(28, (nseg, C))
+    dw = torch.zeros((Ko, 3, 3, C), dtype=torch.float32, device=DEV)
+    K.conv2d_wgrad(to_dev(x, dtype), to_dev(dy, dtype), dw, 3, 3, 1, 1, in_scale=sc.to(DEV), in_shift=sh.to(DEV), in_relu=True,
+                   seg_images=seg)
+    want = torch.zeros((Ko, 3, 3, C))
+    for s in range(nseg):
+        xs = q(F.relu(x[s * seg:(s + 1) * seg] * sc[s] + sh[s]), dtype)
+        want += R.conv_wgrad(xs, dy[s * seg:(s + 1) * seg], (Ko, 3, 3, C), 1, 1)
+    close(dw, want, 2e-4 if dtype == 0 else 3e-3, "segmented wgrad")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("in_u8", [True, False])
 @pytest.mark.parametrize("shape", [(2, 64, 64), (3, 56, 40), (1, 256, 256), (2, 30, 34)])   # W % 4 != 0: byte-staged fallback
 def test_stem(shape, in_u8, dtype):
