@@ -12,7 +12,7 @@ out = sys.argv[1]
 f = glob.glob(out + "/trace/**/t_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # the last optimizer launch ends a step; take the launches between the last two
-idx = [i for i, r in enumerate(rows) if "optimizer_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "optimizer_" in r["Kernel_Name"]]
 lo, hi = idx[-2] + 1, idx[-1] + 1
 t0 = int(rows[lo]["Start_Timestamp"])
 with open(out + "/step.txt", "w") as w:
