@@ -51,6 +51,9 @@ typedef struct sslcr_conv_desc {
      (sum g, sum g*(mask_x - mask_mean[k])) -- the two sums of sslcr_bn_bwd_reduce -- instead of (sum y, sum y^2): the reduce
      pass over (dy, x) of that BatchNorm is not needed. */
   const void* mask_x; const float* mask_scale; const float* mask_shift; const float* mask_mean;
+  int par4;               /* stride-2 3x3 pad-1 dgrad (transposed = 1, pix_mul = 2, PH x PW = the even-sized input / 2): all four
+                             output-parity classes in ONE launch (class = grid z; offsets and tap subsets derived in the kernel)
+                             instead of four launches with pix_off / tap_mask.  DMA-gather kernel shapes only. */
 } sslcr_conv_desc;
 int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream);
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d);

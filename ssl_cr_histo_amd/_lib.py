@@ -26,7 +26,8 @@ ConvDesc = _S("ConvDesc", [("x", vp), ("w", vp), ("y", vp), ("in_scale", vp), ("
                            ("residual", vp), ("stats", vp)] +
               [(k, i32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "PH", "PW", "OH", "OW", "osh",
                                   "transposed", "in_relu", "relu", "accumulate", "pix_mul", "pix_off_h", "pix_off_w")] +
-              [("tap_mask", C.c_uint), ("mask_x", vp), ("mask_scale", vp), ("mask_shift", vp), ("mask_mean", vp)])
+              [("tap_mask", C.c_uint), ("mask_x", vp), ("mask_scale", vp), ("mask_shift", vp), ("mask_mean", vp),
+               ("par4", i32)])
 WgradDesc = _S("WgradDesc", [("x", vp), ("dy", vp), ("dw", vp), ("in_scale", vp), ("in_shift", vp), ("in_relu", i32)] +
                [(k, i32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW", "seg_images", "seg_stride")])
 StemDesc = _S("StemDesc", [("x", vp), ("w", vp), ("y", vp), ("bias", vp), ("stats", vp)] +

@@ -58,7 +58,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   const int pmul = a.pix_mul ? a.pix_mul : 1;
   const int RS = a.R * a.S;
   const int cslabs = a.C / CE;
-  const unsigned tmask = a.tap_mask ? a.tap_mask : ((1u << RS) - 1u);
+  // par4: the four output-parity classes of a stride-2 3x3 dgrad in one launch, heaviest class (4 taps) first
+  int off_h = a.pix_off_h, off_w = a.pix_off_w;
+  unsigned tm4 = 0;
+  if (a.par4) {
+    const int cls = 3 - (int)blockIdx.z;
+    off_h = cls >> 1; off_w = cls & 1;
+    const unsigned mr = off_h ? 5u : 2u, ms = off_w ? 5u : 2u;      // rows / columns r with (off + 1 - r) even
+    tm4 = ((mr & 1u) ? ms : 0u) | ((mr & 2u) ? ms << 3 : 0u) | ((mr & 4u) ? ms << 6 : 0u);
+  }
+  const unsigned tmask = a.par4 ? tm4 : (a.tap_mask ? a.tap_mask : ((1u << RS) - 1u));
   const int nsteps = __builtin_popcount(tmask) * cslabs;
 
   // ---- DMA roles: instruction i of this wave fills LDS rows [i*32 + wave*8, +8); lane -> (row, 16-byte slot)
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     if (m < M) {
       const int n = m / PHW, rem = m - n * PHW;
       int ph = rem / a.PW, pw = rem - ph * a.PW;
-      ph = ph * pmul + a.pix_off_h; pw = pw * pmul + a.pix_off_w;
+      ph = ph * pmul + off_h; pw = pw * pmul + off_w;
       pbase[i] = n * a.H * a.W;
       hb[i] = a.transposed ? ph + a.pad : ph * a.stride - a.pad;
       wb[i] = a.transposed ? pw + a.pad : pw * a.stride - a.pad;
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     const int m = ok[p] ? mm : M - 1;          // a valid pixel for the (unconditional) operand loads
     const int n = m / PHW, rem = m - n * PHW;
     int ph = rem / a.PW, pw = rem - ph * a.PW;
-    ph = ph * pmul + a.pix_off_h; pw = pw * pmul + a.pix_off_w;
+    ph = ph * pmul + off_h; pw = pw * pmul + off_w;
     const size_t opix = ((size_t)n * a.OH + (size_t)ph * a.osh) * a.OW + (size_t)pw * a.osh;
     off[p] = (opix * a.K + kb) * sizeof(T);
   }
@@ -247,7 +256,8 @@ static hipError_t launch_d(const ConvArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(cdiv(M, BP), a.K / BKO), dim3(256), lds, st, a);
+  if (a.par4 && (!a.transposed || a.stride != 2 || a.pix_mul != 2 || a.R != 3 || a.S != 3 || a.pad != 1 || a.stats)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(kern, dim3(cdiv(M, BP), a.K / BKO, a.par4 ? 4 : 1), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 

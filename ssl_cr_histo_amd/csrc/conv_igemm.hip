@@ -338,6 +338,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
   if (tw && conv_halo_tw(DT_BF16, a) == tw) return launch_conv_halo(dtype, a, tw, st);   // (same tiling in both dtypes)
   const int dbp = (q || tw) ? 0 : conv_dma_bp(dtype, a);
   if (dbp && conv_dma_bp(DT_BF16, a) == dbp) return launch_conv_dma(dtype, a, dbp, st);
+  if (a.par4) return hipErrorInvalidValue;          // the one-launch parity form exists in the DMA-gather kernel only
   return dtype == DT_BF16 ? launch_t<bf16_t>(a, st) : launch_t<float>(a, st);
 }
 

@@ -799,8 +799,14 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
           TRY(prof_conv(c, dt,a, st));
         } else {
           // stride-2 dgrad: each input-pixel parity class (ph%2, pw%2) only sees the taps with (p + pad - r) even --
-          // 1 + 2 + 2 + 4 = 9 taps over four launches instead of 36 tap visits with three quarters zero-gathered
-          for (int par = 0; par < 4; ++par) {
+          // 1 + 2 + 2 + 4 = 9 taps instead of 36 tap visits with three quarters zero-gathered; one launch with the class on
+          // grid z where the DMA-gather kernel serves the shape, else four launches
+          ConvArgs q4 = a;
+          q4.pix_mul = 2; q4.PH = xh / 2; q4.PW = xw / 2; q4.par4 = 1;
+          const bool one = xh % 2 == 0 && xw % 2 == 0 && conv_dma_bp(dt, q4) != 0 && conv_dma_bp(DT_BF16, q4) == conv_dma_bp(dt, q4) &&
+                           conv_halo_tw(dt, q4) == 0;
+          if (one) TRY(prof_conv(c, dt, q4, st));
+          for (int par = 0; par < (one ? 0 : 4); ++par) {
             ConvArgs q = a;
             const int ph_ = par >> 1, pw_ = par & 1;
             q.pix_mul = 2; q.pix_off_h = ph_; q.pix_off_w = pw_;

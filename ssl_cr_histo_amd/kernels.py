@@ -36,7 +36,7 @@ last_conv_kernel = ""       # kernel instance the most recent conv2d() launched 
 
 def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bias=None, residual=None, relu=False,
            want_stats=False, out=None, transposed=False, out_hw=None, osh=1, accumulate=False, pixel_hw=None,
-           pix_mul=0, pix_off=(0, 0), tap_mask=0, mask=None):
+           pix_mul=0, pix_off=(0, 0), tap_mask=0, mask=None, par4=False):
     """x NHWC [N,H,W,C], w KRSC [K,R,S,C] -> y NHWC (+ partial stats [rows,2,K] fp32).
 
     transposed=True is the dgrad gather: pixel space = the conv's input (pixel_hw), x = dY, w = [C][R][S][K].
@@ -55,6 +55,7 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
     d = L.ConvDesc(L.ptr(x), L.ptr(w), L.ptr(y), L.ptr(in_scale), L.ptr(in_shift), L.ptr(bias), L.ptr(residual), None,
                    N, H, W, C, K, R, S, stride, pad, PH, PW, OH, OW, osh, int(transposed), int(in_relu), int(relu),
                    int(accumulate), int(pix_mul), int(pix_off[0]), int(pix_off[1]), int(tap_mask))
+    d.par4 = int(par4)
     if mask is not None:
         _chk(*mask)
         d.mask_x, d.mask_scale, d.mask_shift, d.mask_mean = (L.ptr(t) for t in mask)

@@ -165,6 +165,13 @@ def test_conv_dgrad(case, dtype):
                 if N * H * W >= 4 * 2048:
                     assert "conv_dma_kernel" in K.last_conv_kernel, K.last_conv_kernel
             close(dx3, want + res, TOL[dtype], "dgrad by parity classes")
+            if H % 2 == 0 and W % 2 == 0 and N * H * W >= 4 * 2048:
+                # ... and all four classes in one launch (class on grid z): bit-identical to the four launches
+                dx4 = torch.zeros((N, H, W, C), dtype=K.tdtype(dtype), device=DEV)
+                K.conv2d(to_dev(dy, dtype), to_dev(wd, dtype), stride, pad, transposed=True, out=dx4, out_hw=(H, W),
+                         pixel_hw=(H // 2, W // 2), residual=to_dev(res, dtype), pix_mul=2, par4=True)
+                assert "conv_dma_kernel" in K.last_conv_kernel, K.last_conv_kernel
+                assert torch.equal(dx4, dx3)
         if stride == 1:
             # the engine's form: tap-flipped [C][R][S][K] pack => the dgrad is a plain 3x3 conv of dY (halo kernel when it tiles)
             w_kcrs = w.permute(0, 3, 1, 2).contiguous()
