@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--bn-sync", type=int, default=1, choices=[0, 1],
                     help="N>1: 1 = train-mode BatchNorm on global-batch statistics (RCCL all-reduce of per-channel sums, the "
                          "north-star form); 0 = per-replica statistics like the reference's nn.DataParallel (gradient buckets only)")
+    ap.add_argument("--aux-stream", type=int, default=0, choices=[0, 1],
+                    help="1 = teacher forward on a second HIP stream next to the student forward (about -2 %% step time); off by "
+                         "default because concurrent launches make the per-kernel durations of the roofline leg meaningless")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -122,6 +125,7 @@ def main():
     eng = E.set_engine(E.Engine(device, args.dtype))
     sdist.attach_engine(eng)
     eng.set_bn_sync(bool(args.bn_sync))
+    eng.set_aux_stream(bool(args.aux_stream))
 
     hw, b, mu = args.image_size, args.batch_size, args.mu
     lr, wd = 1e-4, 1e-4
@@ -155,7 +159,7 @@ def main():
         cfg = {"workload": f"eval_BreastPathQ_SSL_CR.train step, per-GPU --batch_size {b} --mu {mu}: student {nx}+{nu}, teacher {nu} "
                            f"({patches} distinct {hw}x{hw} uint8 patches/step/GPU), modules_student={args.modules_student}, Adam",
                "global_batch_patches": patches * world, "parallelism": f"dp{world}", "backward": bwd,
-               "bn_sync": bool(args.bn_sync) if world > 1 else None}
+               "bn_sync": bool(args.bn_sync) if world > 1 else None, "aux_stream": bool(args.aux_stream)}
     elif args.workload == "fwd":
         n = 4 * b
         ms, cs = build_nets(args, device)

@@ -239,6 +239,11 @@ int sslcr_comm_init(sslcr_ctx* ctx, const void* id256, int rank, int world);
 /* on (default): synced BatchNorm as described above.  off: every rank normalises with its own shard's statistics -- the
  * semantics of the reference's nn.DataParallel replicas -- and only the gradient buckets are exchanged. */
 int sslcr_set_bn_sync(sslcr_ctx* ctx, int on);
+/* on: sslcr_step_ssl_cr runs the (frozen, eval-mode) teacher forward on a second HIP stream next to the student forward --
+ * the workgroups of one fill the tail rounds of the other's kernels (measured -0.4 ms of a 20.4 ms step).  Off by default:
+ * concurrent launches share the CUs, which makes per-kernel durations (HIP events and rocprofv3 alike) meaningless as a
+ * statement about the kernel, and bench.py's roofline is built from those. */
+int sslcr_set_aux_stream(sslcr_ctx* ctx, int on);
 
 /* measurement: bracket every conv launch of this ctx with HIP events on its own stream (bench.py roofline leg).
  * which = 0: conv_igemm (forward + dgrad), 1: wgrad.  out4 = {launches, total ms, algorithmic FLOPs, algorithmic bytes}.

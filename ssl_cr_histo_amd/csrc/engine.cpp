@@ -124,6 +124,12 @@ struct sslcr_ctx {
   int rank = 0, world = 1;
   int bn_sync = 1;                // train-mode BatchNorm on GLOBAL batch statistics (all-reduce of per-channel sums); 0 = per replica
   hipStream_t comm_stream = nullptr;
+  // second compute stream: the (frozen, eval-mode) teacher forward of an SSL_CR step runs next to the student forward, so the
+  // workgroups of one fill the tail rounds of the other's persistent kernels (the two share no buffers: the teacher works in
+  // ctx scratch, which the student only touches in backward)
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_aux_begin = nullptr, ev_aux_end = nullptr;
+  int use_aux = 0;                // sslcr_set_aux_stream
   hipEvent_t ev_ready[8], ev_done = nullptr;
   DevBuf scratch;     // eval-forward activations and backward transients (never live at the same time)
   DevBuf partials;    // BN partial rows
@@ -922,6 +928,11 @@ int sslcr_create(sslcr_ctx** out, int device, int dtype) {
 int sslcr_destroy(sslcr_ctx* c) {
   if (!c) return 0;
   (void)hipDeviceSynchronize();
+  if (c->aux_stream) {
+    (void)hipStreamDestroy(c->aux_stream);
+    (void)hipEventDestroy(c->ev_aux_begin);
+    (void)hipEventDestroy(c->ev_aux_end);
+  }
   if (c->comm) {
     ncclCommDestroy(c->comm);
     if (c->comm_g) ncclCommDestroy(c->comm_g);
@@ -989,6 +1000,12 @@ int sslcr_comm_unique_id(void* id256) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   TRYN(ncclGetUniqueId((ncclUniqueId*)id256));
   TRYN(ncclGetUniqueId((ncclUniqueId*)((char*)id256 + 128)));
+  return 0;
+}
+
+int sslcr_set_aux_stream(sslcr_ctx* c, int on) {
+  if (!c) return fail("sslcr_set_aux_stream: null");
+  c->use_aux = on ? 1 : 0;
   return 0;
 }
 
@@ -1200,9 +1217,24 @@ int sslcr_step_ssl_cr(sslcr_net* te, sslcr_net* stn, const sslcr_ssl_cr_desc* d,
   hipStream_t st = (hipStream_t)stream;
   const int Ns = d->nx + d->nu;
   TRYI(alloc_heads(stn, Ns));
-  // teacher: eval + no_grad (eval_BreastPathQ_SSL_CR.py:43-44,77-79)
+  // teacher: eval + no_grad (eval_BreastPathQ_SSL_CR.py:43-44,77-79) -- on the second stream when sslcr_set_aux_stream asked
+  // for it (the per-kernel profiler records each launch on the stream it runs on)
+  sslcr_ctx* c = stn->ctx;
+  const bool aux = c->use_aux && te->ctx == c;
+  hipStream_t tst = st;
+  if (aux) {
+    if (!c->aux_stream) {
+      TRY(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+      TRY(hipEventCreateWithFlags(&c->ev_aux_begin, hipEventDisableTiming));
+      TRY(hipEventCreateWithFlags(&c->ev_aux_end, hipEventDisableTiming));
+    }
+    TRY(hipEventRecord(c->ev_aux_begin, st));                 // inputs ready, last step's backward done with the scratch
+    TRY(hipStreamWaitEvent(c->aux_stream, c->ev_aux_begin, 0));
+    tst = c->aux_stream;
+  }
   const void* xt[3] = {d->x_teacher, nullptr, nullptr};
-  TRYI(net_forward(te, 0, xt, d->in_f32, d->nu, d->H, d->W, nullptr, stn->logits_t, st));
+  TRYI(net_forward(te, 0, xt, d->in_f32, d->nu, d->H, d->W, nullptr, stn->logits_t, tst));
+  if (aux) TRY(hipEventRecord(c->ev_aux_end, c->aux_stream));
   // student: train mode on cat(x, u_s) (:82-84)
   const void* xs[3] = {d->x_student, nullptr, nullptr};
   if (d->x_student2 && stn->triplet) return fail("sslcr_step_ssl_cr: split student input needs a single-branch net");
@@ -1210,6 +1242,7 @@ int sslcr_step_ssl_cr(sslcr_net* te, sslcr_net* stn, const sslcr_ssl_cr_desc* d,
   const int frc = net_forward(stn, 1, xs, d->in_f32, Ns, d->H, d->W, d->feats, d->logits, st);
   stn->split_x2 = nullptr; stn->split_n = 0;
   if (frc) return frc;
+  if (aux) TRY(hipStreamWaitEvent(st, c->ev_aux_end, 0));
   LossArgs L;
   memset(&L, 0, sizeof(L));
   L.kind = d->kind; L.logits = stn->logits; L.logits_t = stn->logits_t; L.target_f = d->target_f; L.target_i = d->target_i;

@@ -36,6 +36,7 @@ _ENGINE_SIGS = {
     "sslcr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "sslcr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "sslcr_set_bn_sync": (C.c_int, [C.c_void_p, C.c_int]),
+    "sslcr_set_aux_stream": (C.c_int, [C.c_void_p, C.c_int]),
     "sslcr_net_create": (C.c_int, [C.c_void_p, C.POINTER(SslcrNetDesc), C.POINTER(C.c_void_p)]),
     "sslcr_net_destroy": (C.c_int, [C.c_void_p]),
     "sslcr_net_set_requires_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
@@ -261,6 +262,11 @@ class Engine:
         """True (default): train-mode BatchNorm uses global-batch statistics across ranks; False: per-replica statistics
         like the reference's nn.DataParallel (eval_BreastPathQ_SSL_CR.py:474-477)."""
         L.check(L.lib().sslcr_set_bn_sync(self.handle, int(bool(on))))
+
+    def set_aux_stream(self, on):
+        """True: step_ssl_cr runs the teacher forward on a second stream next to the student forward (-2 % step time; per-kernel
+        timings then include the sharing of the CUs).  Default off."""
+        L.check(L.lib().sslcr_set_aux_stream(self.handle, int(bool(on))))
 
     def _reduce_losses(self, losses):
         """logging only: each rank's (loss, loss_x, loss_u) is already scaled by 1/global-count and #correct is a count,

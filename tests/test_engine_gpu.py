@@ -441,6 +441,35 @@ def test_gradients_vs_oracle(kind, dtype):
     assert not bad, "\n".join(bad)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_aux_stream_teacher_forward_is_the_same_step(dtype):
+    """sslcr_set_aux_stream: the teacher forward on a second stream next to the student forward must not change a bit of
+    the forward results (logits, teacher logits, losses); gradients equal up to the order of the fp32 atomics."""
+    eng = _engine(dtype)
+    hw, nx, nu = 64, 8, 12
+    x, u_w, u_s = C.u8(7101, (nx, 3, hw, hw)), C.u8(7102, (nu, 3, hw, hw)), C.u8(7103, (nu, 3, hw, hw))
+    y = C.f32(7104, (nx,))
+    out = []
+    try:
+        for on in (False, True, True):
+            eng.set_aux_stream(on)
+            mt, ct = build("finetune", "finetune", 1, True)
+            ms, cs = build("finetune", "finetune", 1, True)
+            freeze(mt, 64)
+            te, st = eng.bind(mt, ct), eng.bind(ms, cs)
+            mt.eval()
+            ms.train()
+            r = eng.step_ssl_cr(te, st, "mse", x, y, u_w, u_s, 0.7)
+            torch.cuda.synchronize()
+            out.append((r["losses"].cpu(), r["logits"].cpu(), r["logits_t"].cpu(), [st.grad(i).cpu() for i in (0, 3, 30, 60)]))
+    finally:
+        eng.set_aux_stream(False)
+    for o in out[1:]:
+        assert torch.equal(o[0], out[0][0]) and torch.equal(o[1], out[0][1]) and torch.equal(o[2], out[0][2])
+        for a, b in zip(o[3], out[0][3]):
+            assert rel_err(a, b) < 1e-5
+
+
 def test_deepcopy_teacher_and_state_dict_roundtrip():
     """teacher = copy.deepcopy(student) (eval_BreastPathQ_SSL_CR.py:515-516) and checkpoint key compatibility."""
     eng = _engine("fp32")
