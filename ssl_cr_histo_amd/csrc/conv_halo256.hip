@@ -30,7 +30,7 @@ template <> struct MmaQ<float> {
 // used for K = 64 so that a wave still owns a 64x64 register tile and LDS reads stay at 16 MAC per byte)
 // ONE = the layer has a single channel slab (C == 64 bf16): no halo prefetch registers are kept across the tap loop
 template <typename T, int TW, int BKO, int WK, bool ONE>
-__global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const ConvArgs a, const int tile0) {
   constexpr int NT = 256 * WK;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int CE = 8 * EPC;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
   const int g = lane >> 4, li = lane & 15;
   const int wp = wave & 3, wk = wave >> 2;
   const int tiles_w = a.W / TW, tiles_h = a.H / TH;
-  int tile = blockIdx.x;
+  int tile = blockIdx.x + tile0;             // (tile0: a launch may cover a sub-range of the tiles, see launch_qt)
   const int tw_i = tile % tiles_w; tile /= tiles_w;
   const int th_i = tile % tiles_h;
   const int n0 = (tile / tiles_h) * NI;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
         s2[t * 4 + j] = row16_sum(x2);
       }
     if (li == 0) {
-      float* sp = a.stats + ((size_t)(blockIdx.x * 4 + wp) * 2) * a.K + kb;
+      float* sp = a.stats + ((size_t)((blockIdx.x + tile0) * 4 + wp) * 2) * a.K + kb;
 #pragma unroll
       for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
     }
@@ -315,7 +315,7 @@ int conv_halo256_tiles(const ConvArgs& a, int mode) {
 }
 
 template <typename T, int TW, int BKO, int WK, bool ONE>
-static hipError_t launch_q(const ConvArgs& a, hipStream_t st) {
+static hipError_t launch_q(const ConvArgs& a, hipStream_t st, int tile0 = 0, int ntiles = -1) {
   constexpr int HP = (256 / (TW * TW)) * (TW + 2) * (TW + 2);
   constexpr int TPB = (WK == 2 && !ONE) ? 3 : 1;
   const size_t lds = HP * 128 + 2 * TPB * BKO * 128 + 2 * a.C * sizeof(float);
@@ -326,8 +326,8 @@ static hipError_t launch_q(const ConvArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  dim3 grid(conv_halo256_tiles(a, TW), a.K / BKO);
-  hipLaunchKernelGGL(kern, grid, dim3(256 * WK), lds, st, a);
+  dim3 grid(ntiles < 0 ? conv_halo256_tiles(a, TW) : ntiles, a.K / BKO);
+  hipLaunchKernelGGL(kern, grid, dim3(256 * WK), lds, st, a, tile0);
   return hipGetLastError();
 }
 
@@ -339,7 +339,24 @@ static hipError_t launch_qt(const ConvArgs& a, int mode, hipStream_t st) {
     if (wide) return launch_q<T, 16, 128, 2, false>(a, st);
     return one ? launch_q<T, 16, 64, 1, true>(a, st) : launch_q<T, 16, 64, 2, false>(a, st);
   }
-  if (wide) return launch_q<T, 8, 128, 2, false>(a, st);
+  if (wide) {
+    // one workgroup per CU and (tile, 128-kout block) item: when the last round would occupy at most half the CUs (N=640 at
+    // layer4: 640 items = 2.5 rounds of 256), its tiles run as 64-kout half-items on all of them instead -- ~0.6 of a round
+    // instead of a whole one
+    int cus = 256;
+    {
+      int dev = 0, v = 0;
+      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const int tiles = conv_halo256_tiles(a, 8), kb = a.K / 128, items = tiles * kb, rem = items % cus;
+    if (items > cus && rem != 0 && 2 * rem <= cus && rem % kb == 0) {
+      const int tail = rem / kb;
+      hipError_t e = launch_q<T, 8, 128, 2, false>(a, st, 0, tiles - tail);
+      if (e != hipSuccess) return e;
+      return launch_q<T, 8, 64, 2, false>(a, st, tiles - tail, tail);
+    }
+    return launch_q<T, 8, 128, 2, false>(a, st);
+  }
   return one ? launch_q<T, 8, 64, 1, true>(a, st) : launch_q<T, 8, 64, 2, false>(a, st);
 }
 

@@ -71,6 +71,7 @@ CONV_CASES = [
     (70, 32, 32, 64, 64, 3, 1, 1),     # 128x64 config
     (2, 8, 8, 512, 512, 3, 1, 1),      # halo kernel, 8-wide rows (2 images per tile), 8 channel slabs, BKO 128
     (4, 8, 8, 64, 64, 3, 1, 1),        # halo kernel, 8-wide, single slab
+    (320, 8, 8, 64, 512, 3, 1, 1),     # 80 tiles x 4 kout blocks = 320 items on 256 CUs: the last 64 run as 64-kout half-items
     (2, 16, 32, 128, 128, 3, 1, 1),    # halo kernel, 16-wide, 2 slabs
     (3, 24, 48, 64, 128, 3, 1, 1),     # halo kernel, several tiles per image
     (4, 8, 8, 512, 512, 3, 1, 1),      # 256-pixel halo kernel, 4 images x 8x8, 8 slabs
