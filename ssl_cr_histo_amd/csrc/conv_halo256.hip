@@ -349,10 +349,12 @@ static hipError_t launch_qt(const ConvArgs& a, int mode, hipStream_t st) {
       if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     const int tiles = conv_halo256_tiles(a, 8), kb = a.K / 128, items = tiles * kb, rem = items % cus;
-    if (items > cus && rem != 0 && 2 * rem <= cus && rem % kb == 0) {
+    if (rem != 0 && 2 * rem <= cus && rem % kb == 0) {          // (also the whole launch when it has at most cus / 2 items: N=128)
       const int tail = rem / kb;
-      hipError_t e = launch_q<T, 8, 128, 2, false>(a, st, 0, tiles - tail);
-      if (e != hipSuccess) return e;
+      if (tiles > tail) {
+        hipError_t e = launch_q<T, 8, 128, 2, false>(a, st, 0, tiles - tail);
+        if (e != hipSuccess) return e;
+      }
       return launch_q<T, 8, 64, 2, false>(a, st, tiles - tail, tail);
     }
     return launch_q<T, 8, 128, 2, false>(a, st);
