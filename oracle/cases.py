@@ -44,6 +44,10 @@ CASES = {
                          lambda_u=1.0, opt="adam"),
     # pretrain_BreastPathQ.train/validate: RSP 6-way CE, SGD-Nesterov lr .01 + Lookahead(5,.5) (:245-247)
     "rsp": dict(script="rsp", hw=64, b=4, nb=2, classes=6, lr=0.01, wd=1e-4, opt="sgd"),
+    # one Camelyon SSL_CR iteration (CE + hard pseudo-label CE, SGD-Nesterov) at the size of the benchmark workload:
+    # 2 x 32 x 3 labeled + 2 x 224 weak/strong unlabeled 256x256 patches (student 640, teacher 448); reductions only
+    "cam_cr_full": dict(script="cam_cr", hw=256, b=32, mu=7, nb=1, modules=0, classes=2, lr=5e-4, wd=1e-4,
+                        lambda_u=1.0, opt="sgd"),
     # one RSP iteration at full size (pretrain_BreastPathQ.py defaults: --batch_size 128, 256x256 tiles; 3 x 128 images);
     # golden = reductions only, tests/golden/make_golden.py:gen_rsp_full
     "rsp_full": dict(script="rsp", hw=256, b=128, nb=1, classes=6, lr=0.01, wd=1e-4, opt="sgd"),

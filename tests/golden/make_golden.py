@@ -223,6 +223,40 @@ def gen_cam_cr(name, out):
     out[f"{name}/val"] = np.array(val, dtype=np.float64)
 
 
+def gen_cam_cr_full(name, out):
+    """one iteration of eval_Camelyon_SSL_CR.train at the benchmark size (student 640 / teacher 448 images of 256x256): returned
+    averages, feature reductions, per-parameter gradient norm + seeded +-1 projection of the reference's .grad, snapshot."""
+    c = C.CASES[name]
+    m = importlib.import_module("eval_Camelyon_SSL_CR")
+    mt, ct = build("finetune", "finetune", 2, rand_stats=True)
+    ms, cs = build("finetune", "finetune", 2, rand_stats=True)
+    freeze(mt, 64)
+    freeze(ms, c["modules"])
+    opt = torch.optim.SGD(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())),
+                          lr=c["lr"], momentum=0.9, weight_decay=c["wd"], nesterov=True)
+    torch.manual_seed(777)                     # pins the reference's torch.randperm shuffles (:79-81)
+    ret = m.train(args_ns(lambda_u=c["lambda_u"], image_size=c["hw"]), mt, ms, ct, cs,
+                  C.labeled_batches_cls(name, 1000, 1), C.labeled_batches_cls(name, 1100, 0),
+                  C.unlabeled_batches(name, 2000), C.unlabeled_batches(name, 2100), opt, 1)
+    out[f"{name}/ret"] = np.array(ret[:4], dtype=np.float64)
+    f = ret[4].double()
+    out[f"{name}/feats_shape"] = np.array(f.shape)
+    out[f"{name}/feats_rowl2"] = f.norm(dim=1).numpy()
+    out[f"{name}/feats_colsum"] = f.sum(0).numpy()
+    out[f"{name}/feats_head"] = ret[4][:4].numpy()
+    out[f"{name}/targets"] = ret[5].numpy()
+    names, l2, pr = [], [], []
+    for i, (k, p) in enumerate(list(ms.named_parameters()) + list(cs.named_parameters())):
+        g = p.grad.detach().double().reshape(-1)
+        names.append(k)
+        l2.append(float(g.norm()))
+        pr.append(float((g * C.grad_probe(i, g.numel())).sum()))
+    out[f"{name}/grad_names"] = np.array(names)
+    out[f"{name}/grad_l2"] = np.array(l2)
+    out[f"{name}/grad_probe"] = np.array(pr)
+    snapshot(name, ms, cs, out)
+
+
 def gen_kather_cr(name, out):
     c = C.CASES[name]
     m = importlib.import_module("eval_Kather_SSL_CR")
@@ -363,7 +397,7 @@ def gen_stages(out):
 def main():
     gens = {"bpq_cr_f60": gen_bpq_cr, "bpq_cr_f0": gen_bpq_cr, "cam_cr_f60": gen_cam_cr, "cam_cr_f0": gen_cam_cr,
             "kather_cr_f0": gen_kather_cr, "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup,
-            "cam_wsi": gen_cam_wsi, "bpq_cr_full": gen_bpq_cr_full, "rsp_full": gen_rsp_full}
+            "cam_wsi": gen_cam_wsi, "bpq_cr_full": gen_bpq_cr_full, "rsp_full": gen_rsp_full, "cam_cr_full": gen_cam_cr_full}
     only = sys.argv[1:]
     for name, fn in gens.items():
         if only and name not in only:

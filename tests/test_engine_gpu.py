@@ -254,6 +254,60 @@ def test_cam_wsi_probability_map_vs_reference(dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_cam_cr_full_size_step_vs_reference(dtype):
+    """One Camelyon SSL_CR iteration (cross-entropy + hard pseudo-label cross-entropy, SGD-Nesterov, the reference's three
+    torch.randperm shuffles) at the size of the benchmark workload -- student 640 / teacher 448 images of 256x256 -- against
+    reductions of the reference's own iteration: loss averages and accuracy, feature row norms / column sums, post-step
+    snapshot, and every parameter gradient (norm + seeded +-1 projection of the reference's .grad; the engine keeps the
+    gradients of the last backward, read here after the epoch function returned).  fp32: 1e-3 on losses/features, 5e-3 / 2e-2
+    per gradient norm / projection (two fp32 runs, cf. the float64 yardstick of the BreastPathQ full-size case);
+    bf16: 6e-2 on losses, 0.2 on features, gradient norms within 0.35."""
+    from ssl_cr_histo_amd import steps
+    eng = _engine(dtype)
+    name = "cam_cr_full"
+    c = C.CASES[name]
+    g = load_golden(name)
+    mt, ct = build("finetune", "finetune", 2, True)
+    ms, cs = build("finetune", "finetune", 2, True)
+    freeze(mt, 64)
+    freeze(ms, c["modules"])
+    opt = torch.optim.SGD(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())), lr=c["lr"],
+                          momentum=0.9, weight_decay=c["wd"], nesterov=True)
+    torch.manual_seed(777)
+    ret = steps.cam_cr_train(ns(lambda_u=c["lambda_u"], image_size=c["hw"]), mt, ms, ct, cs,
+                             C.labeled_batches_cls(name, 1000, 1), C.labeled_batches_cls(name, 1100, 0),
+                             C.unlabeled_batches(name, 2000), C.unlabeled_batches(name, 2100), opt, 1)
+    ts, tf, tp = TOLS[dtype]
+    for i in range(3):
+        assert abs(ret[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i]), (i, ret[i], g[f"{name}/ret"][i])
+    f = ret[4].cpu().double()
+    assert list(f.shape) == list(g[f"{name}/feats_shape"])
+    tfe = tf if dtype == "fp32" else 0.2
+    assert rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]) < tfe
+    assert rel_err(f.sum(0), g[f"{name}/feats_colsum"]) < tfe
+    assert rel_err(ret[4][:4].cpu(), g[f"{name}/feats_head"]) < tfe
+    assert torch.equal(ret[5].cpu(), torch.from_numpy(g[f"{name}/targets"]))
+    if dtype == "fp32":
+        assert abs(ret[3] - g[f"{name}/ret"][3]) <= 1.0 / 192 + 1e-9            # accuracy (fraction) over 192 labeled images: at most one flip
+        check_snapshot(g, name, state_of(ms, cs), tp)
+    st = eng.bind(ms, cs)                      # the cached binding of the epoch function: gradients of its last backward
+    names = [str(n) for n in g[f"{name}/grad_names"]]
+    assert names == [k for k, _ in list(ms.named_parameters()) + list(cs.named_parameters())]
+    l2_ref, pr_ref = g[f"{name}/grad_l2"], g[f"{name}/grad_probe"]
+    tol_l2, tol_pr = (5e-3, 2e-2) if dtype == "fp32" else (0.35, 1.5)
+    rows, bad = [], []
+    for i, k in enumerate(names):
+        gr = st.grad(i).cpu().double().reshape(-1)
+        e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
+        e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
+        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}")
+        if e_l2 > tol_l2 or e_pr > tol_pr:
+            bad.append(rows[-1])
+    print(f"[{dtype}] Camelyon full-size gradients vs the reference's .grad:\n" + "\n".join(rows))
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_kather_cr_epoch_vs_reference(dtype):
     from ssl_cr_histo_amd import steps
     _engine(dtype)
