@@ -75,3 +75,44 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
+
+
+def test_ctypes_mirrors_match_the_header_layout(tmp_path):
+    """every ctypes Structure of the Python layer against the C struct it mirrors: same size, same offset of every field
+    (a small C program over include/sslcr.h, compiled with the host gcc).  Fields appended to a descriptor on one side only
+    would otherwise show up as garbage pointers on the GPU."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from ssl_cr_histo_amd import _lib as L
+    from ssl_cr_histo_amd import engine as E
+    if not shutil.which("gcc"):
+        pytest.skip("no host C compiler")
+    pairs = {"sslcr_conv_desc": L.ConvDesc, "sslcr_wgrad_desc": L.WgradDesc, "sslcr_stem_desc": L.StemDesc,
+             "sslcr_stem_wgrad_desc": L.StemWgradDesc, "sslcr_bn_finalize_desc": L.BnFinalizeDesc, "sslcr_bn_act_desc": L.BnActDesc,
+             "sslcr_pool_fwd_desc": L.PoolFwdDesc, "sslcr_pool_bwd_desc": L.PoolBwdDesc, "sslcr_bn_bwd_desc": L.BnBwdDesc,
+             "sslcr_loss_desc": L.LossDesc, "sslcr_tensor_desc": L.TensorDesc, "sslcr_opt_desc": L.OptDesc,
+             "sslcr_pack_desc": L.PackDesc, "sslcr_weak_aug_desc": L.WeakAugDesc}
+    for cname, pyname in (("sslcr_net_desc", "SslcrNetDesc"), ("sslcr_ssl_cr_desc", "SslCrDesc"), ("sslcr_sup_desc", "SupDesc")):
+        assert hasattr(E, pyname), f"engine.py has no ctypes mirror of {cname}"
+        pairs[cname] = getattr(E, pyname)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "sslcr.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'  printf("{cname} . %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    r = subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr          # a field the header does not have fails here, by name
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    want = {}
+    for ln in out.splitlines():
+        cname, fname, v = ln.split()
+        want[(cname, fname)] = int(v)
+    for cname, cls in pairs.items():
+        assert C.sizeof(cls) == want[(cname, ".")], f"sizeof {cname}: header {want[(cname, '.')]} vs ctypes {C.sizeof(cls)}"
+        for fname, _ in cls._fields_:
+            assert getattr(cls, fname).offset == want[(cname, fname)], f"{cname}.{fname}"
