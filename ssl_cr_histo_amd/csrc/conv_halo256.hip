@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
       hreg[i] = v;
     }
   };
+  auto halo_key = [&](int hp) {               // see the comment at hbase below
+    if (TW == 16) return hp & 7;
+    return (hp % HWD) & 7;                     // HH * HWD is a multiple of HWD: the halo column
+  };
   auto store_halo = [&](int slab) {
     // this thread's EPC channels of the slab: read scale/shift ONCE (the compiler cannot hoist LDS reads over the LDS stores)
     float sc[EPC], sh[EPC];
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
         v = Elem<T>::pack(f);
       }
       const int hp = (tid >> 3) + (NT / 8) * i;
-      st16(s_halo + hp * 128 + ((chunk ^ (hp & 7)) << 4), v);
+      st16(s_halo + hp * 128 + ((chunk ^ halo_key(hp)) << 4), v);
     }
   };
   // weights of one (slab, tap): rows k0 .. k0+BKO-1, 128 B each; thread -> (row = tid>>3 (+64), chunk)
@@ -150,6 +154,11 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
     }
   };
 
+  // XOR key of a halo pixel's 16-byte chunks.  16-wide tiles: pixel index & 7 (rows are 18 pixels = even, a fragment's 16 lanes
+  // are 16 consecutive pixels).  8-wide tiles: a fragment's 16 lanes are TWO rows of 8 pixels one 10-pixel halo row apart, and
+  // with the linear key the second row's keys are the first row's shifted by 2 -- every fragment read was a 2-way bank conflict
+  // (27 % of the kernel's LDS cycles by SQ_LDS_BANK_CONFLICT).  key = halo COLUMN & 7 is conflict-free for every tap
+  // (enumerated over all lane groups of ds_read_b128, like the 18-pixel-pitch finding in conv_h16.hip).
   int hbase[TP];
 #pragma unroll
   for (int p = 0; p < TP; ++p) {
@@ -223,7 +232,8 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
 #pragma unroll
         for (int p = 0; p < TP; ++p) {
           const int hp = hbase[p] + toff;
-          bfr[p] = ld16(s_halo + hp * 128 + ((ci ^ (hp & 7)) << 4));
+          const int key = TW == 16 ? (hp & 7) : (((li & 7) + s) & 7);
+          bfr[p] = ld16(s_halo + hp * 128 + ((ci ^ key) << 4));
         }
 #pragma unroll
         for (int t = 0; t < TK; ++t)
