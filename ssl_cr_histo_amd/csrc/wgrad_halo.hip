@@ -30,7 +30,7 @@ __device__ __forceinline__ bf16x8_t tr_pair(const char* p0, const char* p1) {
 //      (dY, halo) buffer is doubled: the next tile is transformed and written to the other buffer in the MIDDLE of this
 //      tile's MFMA loop, one barrier per tile.
 template <typename T, int TW, int KH>
-__global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradArgs a, int tiles_per_split, int ntiles) {
+__global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradArgs a, int tiles_per_split, int ntiles, f32x4_t* partials) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int RB = 64 * sizeof(T);            // LDS bytes per pixel row (64 channels)
@@ -274,6 +274,19 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
     if (NBUF == 2) buf ^= 1;
   }
 
+  if (partials) {
+    // the workgroup's 36 accumulator vectors per thread go to its slab with plain coalesced 16-byte stores; wgrad_fold_kernel
+    // adds the slabs into dW.  As fp32 atomics straight into dW (one resident round of workgroups = 75 MB of 4-byte atomics
+    // per launch, whatever the layer) they were 20-26 % of the kernel: 248 -> 175 us without them on the layer2 shape,
+    // 186 us with these stores.
+    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    f32x4_t* sp = partials + wg * 36 * NT + tid;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) sp[(size_t)(t * 4 + t4) * NT] = acc[t][t4];
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -283,6 +296,63 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
         const int k = k0 + 64 * kh + 16 * t4 + 4 * g + j;
         atomicAdd(a.dw + ((size_t)k * 9 + t) * a.C + c0 + 16 * wave + li, acc[t][t4][j]);
       }
+}
+
+// dW += sum over the pixel splits of the workgroups' accumulator slabs (layout of the store above).  Grid: x = 256-thread
+// blocks over the (kout block, cin block, vector, thread) space, y = chunks of FOLD_Z splits; a thread adds up to FOLD_Z
+// vectors and puts the sum into dW with four fp32 atomics -- 1/FOLD_Z of the atomics the kernel itself would issue, spread
+// over a launch of its own instead of sitting at the end of every workgroup.
+constexpr int FOLD_Z = 16;
+template <int KH>
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const f32x4_t* __restrict__ partials, float* dw, int C, int gx, int gy, int splits) {
+  constexpr int NT = 256 * KH;
+  const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;          // (by, bx, e, tid) flattened, tid fastest
+  const size_t per_wg = (size_t)36 * NT;
+  if (v >= (size_t)gx * gy * per_wg) return;
+  const int tid = (int)(v % NT);
+  const int e = (int)((v / NT) % 36);
+  const int bxy = (int)(v / per_wg);
+  const int bx = bxy % gx, by = bxy / gx;
+  const int z0 = blockIdx.y * FOLD_Z, z1 = min(splits, z0 + FOLD_Z);
+  f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+  const f32x4_t* p = partials + (((size_t)z0 * gy + by) * gx + bx) * per_wg + (size_t)e * NT + tid;
+  const size_t zstride = (size_t)gy * gx * per_wg;
+  for (int z = z0; z < z1; ++z, p += zstride) {
+    const f32x4_t q = __builtin_nontemporal_load(p);
+    sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2]; sum[3] += q[3];
+  }
+  const int lane = tid & 63, wave = (tid >> 6) & 3, kh = tid >> 8;
+  const int li = lane & 15, g = lane >> 4;
+  const int t = e >> 2, t4 = e & 3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = bx * 64 * KH + 64 * kh + 16 * t4 + 4 * g + j;
+    atomicAdd(dw + ((size_t)k * 9 + t) * C + by * 64 + 16 * wave + li, sum[j]);
+  }
+}
+
+// slabs of the launches on one stream (a launch's fold has consumed them before the next launch on that stream writes)
+static f32x4_t* wgrad_slabs(hipStream_t st, size_t bytes) {
+  struct Slab { hipStream_t st; void* p; size_t cap; };
+  static Slab slabs[8];
+  static int n = 0;
+  for (int i = 0; i < n; ++i)
+    if (slabs[i].st == st) {
+      if (slabs[i].cap < bytes) {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(slabs[i].p);
+        slabs[i].p = nullptr; slabs[i].cap = 0;
+        if (hipMalloc(&slabs[i].p, bytes) != hipSuccess) return nullptr;
+        slabs[i].cap = bytes;
+      }
+      return reinterpret_cast<f32x4_t*>(slabs[i].p);
+    }
+  if (n == 8) return nullptr;                    // more streams than slots: that launch falls back to atomics
+  Slab s{st, nullptr, 0};
+  if (hipMalloc(&s.p, bytes) != hipSuccess) return nullptr;
+  s.cap = bytes;
+  slabs[n++] = s;
+  return reinterpret_cast<f32x4_t*>(s.p);
 }
 
 int wgrad_halo_tw(const WgradArgs& a) {
@@ -325,7 +395,15 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.K / (64 * KH), a.C / 64, splits), dim3(256 * KH), lds, st, a, tps, ntiles);
+  const int gx = a.K / (64 * KH), gy = a.C / 64;
+  // accumulator slabs + a fold launch instead of atomics from the kernel, when there is more than one split to fold
+  f32x4_t* slabs = (BF && splits > 1) ? wgrad_slabs(st, (size_t)gx * gy * splits * 36 * 256 * KH * sizeof(f32x4_t)) : nullptr;
+  hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(256 * KH), lds, st, a, tps, ntiles, slabs);
+  if (slabs) {
+    const size_t nvec = (size_t)gx * gy * 36 * 256 * KH;
+    hipLaunchKernelGGL(wgrad_fold_kernel<KH>, dim3((unsigned)cdiv((int)nvec, 256), cdiv(splits, FOLD_Z)), dim3(256), 0, st, slabs, a.dw, a.C, gx,
+                       gy, splits);
+  }
   return hipGetLastError();
 }
 
