@@ -29,7 +29,7 @@ template <> struct WgFrag<bf16_t> {
 };
 
 template <typename T, int TAPS>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int steps_per_split) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int steps_per_split, f32x4_t* partials) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int PS = BF ? 32 : 16;             // pixels per step
@@ -59,7 +59,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int st
   const int total_steps = (M + PS - 1) / PS;
   int nsteps = total_steps - step0;
   if (nsteps > steps_per_split) nsteps = steps_per_split;
-  if (nsteps <= 0) return;
+  if (nsteps <= 0) {                            // (the launcher sizes the splits so that none is empty; a slab must still be defined)
+    if (partials) {
+      const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      for (int e = 0; e < TAPS * 4; ++e) partials[(wg * (TAPS * 4) + e) * 256 + tid] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
 
   const char* xg = reinterpret_cast<const char*>(a.x);
   const char* dyg = reinterpret_cast<const char*>(a.dy);
@@ -152,6 +158,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int st
 
   // acc[tap][t4]: D[row = kout 16*t4+4g+j][col = cin 16*wave+li]  ->  dW[k][tap][c]
   const int RS = a.R * a.S;
+  if (partials) {                               // accumulator slab + fold launch instead of atomics from here, see wgrad_halo.hip
+    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    f32x4_t* sp = partials + wg * (TAPS * 4) * 256 + tid;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int t4 = 0; t4 < 4; ++t4) sp[(size_t)(t * 4 + t4) * 256] = acc[t][t4];
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
@@ -189,7 +204,11 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.K / 64, a.C / 64, splits), dim3(256), lds, st, a, sps);
+  const int gx = a.K / 64, gy = a.C / 64;
+  f32x4_t* slabs = (Elem<T>::DT == DT_BF16 && splits > 1 && TAPS == a.R * a.S)
+                       ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * TAPS * 4 * 256 * sizeof(f32x4_t))) : nullptr;
+  hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(256), lds, st, a, sps, slabs);
+  if (slabs) return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, TAPS, 1, st);
   return hipGetLastError();
 }
 

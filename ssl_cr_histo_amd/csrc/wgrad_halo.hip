@@ -74,7 +74,13 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
   const int t_begin = blockIdx.z * tiles_per_split;
   int t_end = t_begin + tiles_per_split;
   if (t_end > ntiles) t_end = ntiles;
-  if (t_begin >= t_end) return;
+  if (t_begin >= t_end) {                       // (the launcher sizes the splits so that none is empty; a slab must still be defined)
+    if (partials) {
+      const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      for (int e = 0; e < 36; ++e) partials[(wg * 36 + e) * NT + tid] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
   const char* xg = reinterpret_cast<const char*>(a.x);
   const char* dyg = reinterpret_cast<const char*>(a.dy);
 
@@ -303,14 +309,14 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
 // vectors and puts the sum into dW with four fp32 atomics -- 1/FOLD_Z of the atomics the kernel itself would issue, spread
 // over a launch of its own instead of sitting at the end of every workgroup.
 constexpr int FOLD_Z = 16;
-template <int KH>
-__global__ __launch_bounds__(256) void wgrad_fold_kernel(const f32x4_t* __restrict__ partials, float* dw, int C, int gx, int gy, int splits) {
-  constexpr int NT = 256 * KH;
+__global__ __launch_bounds__(256) void wgrad_fold_kernel(const f32x4_t* __restrict__ partials, float* dw, int C, int gx, int gy, int splits,
+                                                        int taps, int kh_n) {
+  const int NT = 256 * kh_n, ev = taps * 4;                         // threads per workgroup, accumulator vectors per thread
   const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;          // (by, bx, e, tid) flattened, tid fastest
-  const size_t per_wg = (size_t)36 * NT;
+  const size_t per_wg = (size_t)ev * NT;
   if (v >= (size_t)gx * gy * per_wg) return;
   const int tid = (int)(v % NT);
-  const int e = (int)((v / NT) % 36);
+  const int e = (int)((v / NT) % ev);
   const int bxy = (int)(v / per_wg);
   const int bx = bxy % gx, by = bxy / gx;
   const int z0 = blockIdx.y * FOLD_Z, z1 = min(splits, z0 + FOLD_Z);
@@ -326,13 +332,19 @@ __global__ __launch_bounds__(256) void wgrad_fold_kernel(const f32x4_t* __restri
   const int t = e >> 2, t4 = e & 3;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int k = bx * 64 * KH + 64 * kh + 16 * t4 + 4 * g + j;
-    atomicAdd(dw + ((size_t)k * 9 + t) * C + by * 64 + 16 * wave + li, sum[j]);
+    const int k = bx * 64 * kh_n + 64 * kh + 16 * t4 + 4 * g + j;
+    atomicAdd(dw + ((size_t)k * taps + t) * C + by * 64 + 16 * wave + li, sum[j]);
   }
+}
+hipError_t launch_wgrad_fold(const void* slabs, float* dw, int C, int gx, int gy, int splits, int taps, int kh_n, hipStream_t st) {
+  const size_t nvec = (size_t)gx * gy * taps * 4 * 256 * kh_n;
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((nvec + 255) / 256), cdiv(splits, FOLD_Z)), dim3(256), 0, st,
+                     reinterpret_cast<const f32x4_t*>(slabs), dw, C, gx, gy, splits, taps, kh_n);
+  return hipGetLastError();
 }
 
 // slabs of the launches on one stream (a launch's fold has consumed them before the next launch on that stream writes)
-static f32x4_t* wgrad_slabs(hipStream_t st, size_t bytes) {
+void* wgrad_slabs(hipStream_t st, size_t bytes) {
   struct Slab { hipStream_t st; void* p; size_t cap; };
   static Slab slabs[8];
   static int n = 0;
@@ -345,14 +357,14 @@ static f32x4_t* wgrad_slabs(hipStream_t st, size_t bytes) {
         if (hipMalloc(&slabs[i].p, bytes) != hipSuccess) return nullptr;
         slabs[i].cap = bytes;
       }
-      return reinterpret_cast<f32x4_t*>(slabs[i].p);
+      return slabs[i].p;
     }
   if (n == 8) return nullptr;                    // more streams than slots: that launch falls back to atomics
   Slab s{st, nullptr, 0};
   if (hipMalloc(&s.p, bytes) != hipSuccess) return nullptr;
   s.cap = bytes;
   slabs[n++] = s;
-  return reinterpret_cast<f32x4_t*>(s.p);
+  return s.p;
 }
 
 int wgrad_halo_tw(const WgradArgs& a) {
@@ -397,13 +409,9 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   }
   const int gx = a.K / (64 * KH), gy = a.C / 64;
   // accumulator slabs + a fold launch instead of atomics from the kernel, when there is more than one split to fold
-  f32x4_t* slabs = (BF && splits > 1) ? wgrad_slabs(st, (size_t)gx * gy * splits * 36 * 256 * KH * sizeof(f32x4_t)) : nullptr;
+  f32x4_t* slabs = (BF && splits > 1) ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * 36 * 256 * KH * sizeof(f32x4_t))) : nullptr;
   hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(256 * KH), lds, st, a, tps, ntiles, slabs);
-  if (slabs) {
-    const size_t nvec = (size_t)gx * gy * 36 * 256 * KH;
-    hipLaunchKernelGGL(wgrad_fold_kernel<KH>, dim3((unsigned)cdiv((int)nvec, 256), cdiv(splits, FOLD_Z)), dim3(256), 0, st, slabs, a.dw, a.C, gx,
-                       gy, splits);
-  }
+  if (slabs) return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, 9, KH, st);
   return hipGetLastError();
 }
 
