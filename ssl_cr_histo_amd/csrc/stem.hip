@@ -332,7 +332,7 @@ hipError_t launch_stem(int dtype, const StemArgs& a, hipStream_t st) {
 // D[kout][feature (r,s8,c4)] = sum_pixels dY^T[kout][pixel] * patch[pixel][feature]; the patch operand is read straight
 // out of the halo with per-lane addresses (ds_read_b64_tr_b16 delivers the pixel-major -> K-major transpose for free).
 template <typename T, bool INF32>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, int tiles_h, int tiles_w, int ntiles) {
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, int tiles_h, int tiles_w, int ntiles, f32x4_t* partials) {
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int PS = BF ? 32 : 16;               // pixels per MFMA depth step
@@ -442,6 +442,14 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
     __syncthreads();
     cur ^= 1;
   }
+  if (partials) {
+    // every workgroup adds into the SAME 64 x 147 weights: as atomics that is up to 768 adds per address.  Slab + fold launch
+    // instead (see wgrad_halo.hip)
+    f32x4_t* sp = partials + (size_t)blockIdx.x * 14 * 256 + threadIdx.x;
+#pragma unroll
+    for (int f = 0; f < 14; ++f) sp[f * 256] = acc[f];
+    return;
+  }
   // D[row = kout 16*wave+4g+j][col = feature li -> (s = s0 + li>>2, c = li&3)] -> dW[k][c][r][s]
 #pragma unroll
   for (int f = 0; f < 14; ++f) {
@@ -453,6 +461,23 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
         atomicAdd(a.dw + ((k * 3 + c) * 7 + r) * 7 + s, acc[f][j]);
       }
     }
+  }
+}
+
+// dW += sum of the workgroups' slabs: block (x = accumulator vector f, y = chunk of 16 workgroups), thread = the kernel's thread
+__global__ __launch_bounds__(256) void stem_wgrad_fold_kernel(const f32x4_t* __restrict__ partials, float* dw, int nwg) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int z0 = blockIdx.y * 16, z1 = min(nwg, z0 + 16);
+  f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
+  for (int z = z0; z < z1; ++z) {
+    const f32x4_t q = partials[((size_t)z * 14 + f) * 256 + tid];
+    sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2]; sum[3] += q[3];
+  }
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
+  const int r = f >> 1, s = (f & 1) * 4 + (li >> 2), c = li & 3;
+  if (s < 7 && c < 3) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(dw + (((16 * wave + 4 * g + j) * 3 + c) * 7 + r) * 7 + s, sum[j]);
   }
 }
 
@@ -470,7 +495,9 @@ static hipError_t launch_stem_wgrad_t(const StemWgradArgs& a, hipStream_t st) {
     attr_done = true;
   }
   int grid = ntiles < 768 ? ntiles : 768;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, th, tw, ntiles);
+  f32x4_t* slabs = (Elem<T>::DT == DT_BF16 && grid > 16) ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t))) : nullptr;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, th, tw, ntiles, slabs);
+  if (slabs) hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3(14, cdiv(grid, 16)), dim3(256), 0, st, slabs, a.dw, grid);
   return hipGetLastError();
 }
 
