@@ -462,12 +462,16 @@ __device__ __forceinline__ void bn_bwd_param_grads(const BnBwdArgs& a) {
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
+// NB threads per workgroup.  The per-channel sums end in fp64 atomics on 2C addresses, and atomics on ONE address serialise:
+// with 1024 workgroups of 256 threads each address took 1024 of them, ~18 us at the end of every launch (0.36 ms per step by
+// ablation).  Same number of waves as 256 workgroups of 1024 threads: a quarter of the chain.
+template <typename T, int NB>
+__global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   constexpr int EPC = Elem<T>::EPC;
-  __shared__ float sm[256][2 * EPC + 1];
+  extern __shared__ __attribute__((aligned(16))) char bn_red_smem[];
+  float (*sm)[2 * EPC + 1] = reinterpret_cast<float (*)[2 * EPC + 1]>(bn_red_smem);
   const int cols = a.C / EPC;                 // <= 256 and a power of two for resnet18
-  const int rpp = 256 / cols;                 // pixel rows per pass
+  const int rpp = NB / cols;                  // pixel rows per pass
   const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
   const int cb = col * EPC;
   // per-channel constants of this thread's EPC channels live in registers for the whole grid-stride loop (re-reading them per
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
   for (int e = 0; e < EPC; ++e) { sm[threadIdx.x][e] = s0[e]; sm[threadIdx.x][EPC + e] = s1[e]; }
   __syncthreads();
   // thread t < cols*2*EPC: (col, which/e) sums over rl
-  for (int t = threadIdx.x; t < cols * 2 * EPC; t += 256) {
+  for (int t = threadIdx.x; t < cols * 2 * EPC; t += NB) {
     const int cc = t / (2 * EPC), q = t - cc * 2 * EPC;
     double acc = 0.0;
     for (int r = 0; r < rpp; ++r) acc += (double)sm[r * cols + cc][q];
@@ -695,10 +699,27 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<float>, dim3((int)blocks), dim3(256), 0, st, a);
     return hipGetLastError();
   }
+  if (blocks >= 512) {                 // big tensors: a quarter of the workgroups, four times the threads each
+    constexpr int NB = 1024;
+    const int rpp4 = NB / cols;
+    size_t b4 = ((a.pixels + rpp4 - 1) / rpp4 + 7) / 8;
+    if (b4 > 256) b4 = 256;
+    const size_t lds = (size_t)NB * (2 * epc + 1) * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_reduce_kernel<bf16_t, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_reduce_kernel<float, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_done = true;
+    }
+    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 1024>), dim3((int)b4), dim3(NB), lds, st, a);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3((int)b4), dim3(NB), lds, st, a);
+    return hipGetLastError();
+  }
+  const size_t lds = (size_t)256 * (2 * epc + 1) * sizeof(float);
   if (dtype == DT_BF16) {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 256>), dim3((int)blocks), dim3(256), lds, st, a);
   } else {
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3((int)blocks), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 256>), dim3((int)blocks), dim3(256), lds, st, a);
   }
   return hipGetLastError();
 }
