@@ -8,6 +8,8 @@
 // all nine taps fetch their B fragments from the halo at shifted pixel addresses -- ds_read_b64_tr_b16 takes a per-lane
 // address, so the shift is free.  4.3x less staging traffic per MAC.  Same 64(kout) x 64(cin) x 9 register tile, wave w
 // owning cin tile w; fp32 hardware atomics into dW.
+#include <mutex>
+
 #include "kernels.hpp"
 
 namespace sslcr {
@@ -348,6 +350,8 @@ void* wgrad_slabs(hipStream_t st, size_t bytes) {
   struct Slab { hipStream_t st; void* p; size_t cap; };
   static Slab slabs[8];
   static int n = 0;
+  static std::mutex mu;                          // host threads driving different streams
+  std::lock_guard<std::mutex> lock(mu);
   for (int i = 0; i < n; ++i)
     if (slabs[i].st == st) {
       if (slabs[i].cap < bytes) {
