@@ -1149,7 +1149,11 @@ int sslcr_net_optimizer_step(sslcr_net* n, const sslcr_opt_desc* o, float* const
       }
       // work list: OPT_CHUNK elements per entry
       const int ti = (int)n->host_descs.size();
-      for (int e = 0; e < t.n; e += OPT_CHUNK) host_chunks.push_back({ti, e});
+      if (t.K > 0 && t.RS == 9 && t.w_fwd && t.w_dgrad && t.K % 16 == 0 && t.C % 16 == 0) {
+        for (int tile = 0; tile < (t.K / 16) * (t.C / 16); ++tile) host_chunks.push_back({ti, -(tile + 1)});   // LDS-transposed tiles
+      } else {
+        for (int e = 0; e < t.n; e += OPT_CHUNK) host_chunks.push_back({ti, e});
+      }
       n->host_descs.push_back(t);
       if (t.n > n->max_n) n->max_n = t.n;
     }

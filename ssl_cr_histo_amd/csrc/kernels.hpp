@@ -77,6 +77,7 @@ hipError_t launch_weak_augment(const sslcr_weak_aug_desc& a, hipStream_t st);
 // optim.hip
 hipError_t launch_optimizer(const TensorDesc* d_descs, int ntensors, int max_n, const OptArgs& o, hipStream_t st);
 constexpr int OPT_CHUNK = 2048;     // elements per work-list entry
+constexpr int OPT_TILE = 16 * 16 * 9; // ... and per LDS-transposed 3x3 filter tile (chunk.y = -(tile + 1))
 hipError_t launch_optimizer_chunks(const TensorDesc* d_descs, const void* d_chunks /* int2 {tensor, first element} */, int nchunks,
                                    const OptArgs& o, hipStream_t st);
 hipError_t launch_axpby(float* p, float* q, size_t n, float alpha, int copy_back, hipStream_t st);

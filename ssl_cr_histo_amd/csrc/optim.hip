@@ -6,9 +6,14 @@
 namespace sslcr {
 
 // one parameter element: i indexes p / s1 / s2, gi the gradient.  Returns the new value.
+__device__ __forceinline__ float opt_update_g(const TensorDesc& d, const OptArgs& o, int i, float graw);
 __device__ __forceinline__ float opt_update(const TensorDesc& d, const OptArgs& o, int i, int gi) {
+  return opt_update_g(d, o, i, d.g[gi]);
+}
+// ... with the raw gradient element already in hand
+__device__ __forceinline__ float opt_update_g(const TensorDesc& d, const OptArgs& o, int i, float graw) {
   float p = d.p[i];
-  const float g = fmaf(o.wd, p, d.g[gi] * o.grad_scale);
+  const float g = fmaf(o.wd, p, graw * o.grad_scale);
   if (o.kind == 0) {                  // Adam, L2 decay in the gradient, eps outside the sqrt
     float m = d.s1[i], v = d.s2[i];
     m = fmaf(o.beta1, m, (1.f - o.beta1) * g);
@@ -72,7 +77,52 @@ __global__ __launch_bounds__(256) void optimizer_chunks_kernel(const TensorDesc*
                                                                const OptArgs o) {
   const int2 ch = chunks[blockIdx.x];
   const TensorDesc d = descs[ch.x];
-  if (d.K > 0) {
+  if (ch.y < 0) {
+    // 3x3 filter with shadow weights, tile (16 kout) x (16 cin) x 9 taps = 2304 elements through LDS, so that EVERY stream is
+    // a run of >= 32 bytes: gradient [K][9][C] in (64-byte runs of 16 cin), parameter / moments [K][C][9] (576-byte runs),
+    // forward weights [K][9][C] and dgrad weights [C][9][K] out (32-byte runs).  In parameter order three of the five
+    // streams were 2- and 4-byte accesses a filter row apart (the kernel ran at 1.6 TB/s).
+    __shared__ float sm[16 * 145];               // parameter order, one pad word per kout: kl * 145 + cl * 9 + rs
+    const int tile = -ch.y - 1, ctiles = d.C / 16;
+    const int k0 = (tile / ctiles) * 16, c0 = (tile % ctiles) * 16;
+#pragma unroll
+    for (int j = 0; j < OPT_TILE / 256; ++j) {     // gradient order in
+      const int e = threadIdx.x + 256 * j;
+      const int cl = e & 15, t2 = e >> 4, kl = t2 / 9, rs = t2 - kl * 9;
+      sm[kl * 145 + cl * 9 + rs] = d.g[((size_t)(k0 + kl) * 9 + rs) * d.C + c0 + cl];
+    }
+    __syncthreads();
+    float pv[OPT_TILE / 256];
+#pragma unroll
+    for (int j = 0; j < OPT_TILE / 256; ++j) {     // parameter order: the update
+      const int e = threadIdx.x + 256 * j;
+      const int kl = e / 144, rem = e - kl * 144;
+      pv[j] = opt_update_g(d, o, ((k0 + kl) * d.C + c0) * 9 + rem, sm[e + kl]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < OPT_TILE / 256; ++j) { const int e = threadIdx.x + 256 * j; sm[e + e / 144] = pv[j]; }
+    __syncthreads();
+    const bool bf = d.pack_dtype == DT_BF16;
+#pragma unroll
+    for (int j = 0; j < OPT_TILE / 256; ++j) {     // forward weights out: [k][rs][c]
+      const int e = threadIdx.x + 256 * j;
+      const int cl = e & 15, t2 = e >> 4, kl = t2 / 9, rs = t2 - kl * 9;
+      const float p = sm[kl * 145 + cl * 9 + rs];
+      const size_t oo = ((size_t)(k0 + kl) * 9 + rs) * d.C + c0 + cl;
+      if (bf) Elem<bf16_t>::st(reinterpret_cast<bf16_t*>(d.w_fwd) + oo, p);
+      else reinterpret_cast<float*>(d.w_fwd)[oo] = p;
+    }
+#pragma unroll
+    for (int j = 0; j < OPT_TILE / 256; ++j) {     // dgrad weights out: [c][rs'][k]
+      const int e = threadIdx.x + 256 * j;
+      const int kl = e & 15, t2 = e >> 4, cl = t2 / 9, rs = t2 - cl * 9;
+      const float p = sm[kl * 145 + cl * 9 + rs];
+      const size_t oo = ((size_t)(c0 + cl) * 9 + (d.dgrad_flip ? 8 - rs : rs)) * d.K + k0 + kl;
+      if (bf) Elem<bf16_t>::st(reinterpret_cast<bf16_t*>(d.w_dgrad) + oo, p);
+      else reinterpret_cast<float*>(d.w_dgrad)[oo] = p;
+    }
+  } else if (d.K > 0) {
     // parameter order (p, s1, s2 coalesced); the gradient gather and the two shadow-weight writes are the strided streams
     const int crs = d.C * d.RS;
     const int end = ch.y + OPT_CHUNK < d.n ? ch.y + OPT_CHUNK : d.n;
