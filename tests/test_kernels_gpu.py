@@ -407,6 +407,26 @@ def test_bn_relu_maxpool_shapes(hw, C, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+def test_bn_relu_maxpool_many_rows(dtype):
+    """4160 output rows (more than the row form's 4096-workgroup grid, so workgroups walk several rows); argmax codes against torch."""
+    K = _k()
+    N, H, W, C = 130, 64, 64, 64
+    x = q(rnd(65, (N, H, W, C), 2.0), dtype)
+    sc, sh = rnd(66, (C,)), rnd(67, (C,))
+    pooled, am = K.bn_relu_maxpool(to_dev(x, dtype), sc.to(DEV), sh.to(DEV))
+    act = F.relu(R.nchw(x) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    ref, idx = F.max_pool2d(act, 3, 2, 1, return_indices=True)
+    close(pooled, R.nhwc(ref), 1e-6 if dtype == 0 else 1e-2, "maxpool values")
+    if dtype == 0:
+        # the argmax codes (window position r*3+s) point at the element torch picked wherever the maximum is unique
+        am = am.cpu().to(torch.int64).reshape(N, H // 2, W // 2, C)
+        oh = torch.arange(H // 2).view(1, -1, 1, 1); ow = torch.arange(W // 2).view(1, 1, -1, 1)
+        flat = (2 * oh - 1 + am // 3) * W + (2 * ow - 1 + am % 3)
+        pos = R.nhwc(ref) > 0
+        assert torch.equal(flat[pos], R.nhwc(idx)[pos])
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("mode", ["yact", "from_x", "none"])
 def test_bn_backward(mode, dtype):
     K = _k()
