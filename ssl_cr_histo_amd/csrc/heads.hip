@@ -13,10 +13,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, int relu, int accumulate) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, g = lane >> 4;
+  // one 16x16 tile per workgroup, K split over its four waves in interleaved 64-wide chunks and folded through LDS: these
+  // GEMMs are latency-bound (a dependent memory round trip per 64 of K, M*N of a few hundred tiles), and a wave per tile
+  // walked K = 1024 in 16 serial trips
+  __shared__ float red[3][64][4];
   const int tiles_n = (N + 15) / 16;
-  const int tile = blockIdx.x * 4 + wave;
+  const int tile = blockIdx.x;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  if (tm * 16 >= M) return;
   const int i = tm * 16 + li, j = tn * 16 + li;
   const bool iv = i < M, jv = j < N;
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -24,7 +27,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   // a full memory round trip per 4 MFMAs); operands contiguous in k are fetched as one 16-byte load per lane
   const bool avec = sa_k == 1 && (sa_i & 3) == 0 && ((size_t)A & 15) == 0;
   const bool bvec = sb_k == 1 && (sb_j & 3) == 0 && ((size_t)B & 15) == 0;
-  for (int kb = 0; kb < K; kb += 64) {
+  for (int kb = wave * 64; kb < K; kb += 256) {
     float a[4][4], b[4][4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -51,6 +54,16 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], b[u][e], acc, 0, 0, 0);
   }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave - 1][lane][r] = acc[r];
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += red[w][lane][r];
   // D[row = 4g + r][col = li]
   if (jv) {
     const float bj = bias ? bias[j] : 0.f;
@@ -71,7 +84,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 static hipError_t gemm(const float* A, long sa_i, long sa_k, const float* B, long sb_k, long sb_j, float* C, int M, int N, int K,
                        const float* bias, int relu, int accumulate, hipStream_t st) {
   const int tiles = cdiv(M, 16) * cdiv(N, 16);
-  hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(tiles, 4)), dim3(256), 0, st, A, sa_i, sa_k, B, sb_k, sb_j, C, M, N, K, bias, relu, accumulate);
+  hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, st, A, sa_i, sa_k, B, sb_k, sb_j, C, M, N, K, bias, relu, accumulate);
   return hipGetLastError();
 }
 
