@@ -572,12 +572,20 @@ int heads_forward(sslcr_net* n, float* const* E, int npass, int N, hipStream_t s
   for (int i = 0; i < nh; ++i) {
     const float* Ea = E[npass == 3 ? kPairs[i][0] : 0];
     const float* Eb = E[npass == 3 ? kPairs[i][1] : 0];
-    TRY(launch_copy2d(n->cat[i], 1024, Ea, 512, N, 512, 0, st));
-    TRY(launch_copy2d(n->cat[i] + 512, 1024, Eb, 512, N, 512, 0, st));
+    if (Ea == Eb) {
+      TRY(launch_copy2d_multi(n->cat[i], 1024, 2, 512, Ea, 512, 1, 0, N, 512, st));
+    } else {
+      TRY(launch_copy2d(n->cat[i], 1024, Ea, 512, N, 512, 0, st));
+      TRY(launch_copy2d(n->cat[i] + 512, 1024, Eb, 512, N, 512, 0, st));
+    }
     TRY(launch_linear_fwd(n->cat[i], w0, b0, n->hact[i], N, 512, 1024, 1, st));
     TRY(launch_linear_fwd(n->hact[i], w2, b2, n->fi[i], N, 256, 512, 0, st));
   }
-  for (int i = 0; i < 3; ++i) TRY(launch_copy2d(n->feats + 256 * i, 768, n->fi[nh == 3 ? i : 0], 256, N, 256, 0, st));
+  if (nh == 1) {
+    TRY(launch_copy2d_multi(n->feats, 768, 3, 256, n->fi[0], 256, 1, 0, N, 256, st));
+  } else {
+    for (int i = 0; i < 3; ++i) TRY(launch_copy2d(n->feats + 256 * i, 768, n->fi[i], 256, N, 256, 0, st));
+  }
   if (n->head_kind == 0) {
     TRY(launch_linear_fwd(n->feats, n->params[64], n->params[65], n->logits, N, n->ncls, 768, 0, st));
   } else {
@@ -603,18 +611,20 @@ int heads_backward(sslcr_net* n, const float* dlogits, int npass, int N, bool ne
   }
   if (!any_fc && !need_dE) return 0;
   const int nh = (npass == 3) ? 3 : 1;
-  if (need_dE)
+  if (need_dE && nh == 3)
     for (int i = 0; i < npass; ++i) TRY(hipMemsetAsync(n->dE[i], 0, (size_t)N * 512 * 4, st));
   for (int i = 0; i < nh; ++i) {
     if (nh == 3) {
       TRY(launch_copy2d(n->dtmp256, 256, n->dfeats + 256 * i, 768, N, 256, 0, st));
     } else {   // the three identical branches of TripletNet_Finetune: gradients add (models/net.py:96-100)
-      for (int j = 0; j < 3; ++j) TRY(launch_copy2d(n->dtmp256, 256, n->dfeats + 256 * j, 768, N, 256, j > 0, st));
+      TRY(launch_copy2d_multi(n->dtmp256, 256, 1, 0, n->dfeats, 768, 3, 256, N, 256, st));
     }
     TRY(launch_linear_bwd(n->hact[i], w2, n->dtmp256, nullptr, n->dtmp512, gptr(n, 62), gptr(n, 63), N, 256, 512, 0, n->scratch, st));
     TRY(launch_linear_bwd(n->cat[i], w0, n->dtmp512, n->hact[i], need_dE ? n->dcat : nullptr, gptr(n, 60), gptr(n, 61), N, 512, 1024, 0,
                           n->scratch, st));
-    if (need_dE) {
+    if (need_dE && nh == 1) {                    // both halves of [E, E] are the one embedding: dE = left + right
+      TRY(launch_copy2d_multi(n->dE[0], 512, 1, 0, n->dcat, 1024, 2, 512, N, 512, st));
+    } else if (need_dE) {
       const int a = nh == 3 ? kPairs[i][0] : 0, b = nh == 3 ? kPairs[i][1] : 0;
       TRY(launch_copy2d(n->dE[a], 512, n->dcat, 1024, N, 512, 1, st));
       TRY(launch_copy2d(n->dE[b], 512, n->dcat + 512, 1024, N, 512, 1, st));

@@ -85,6 +85,8 @@ hipError_t launch_fill(float* p, size_t n, float v, hipStream_t st);
 hipError_t launch_pack_conv(int dtype, const PackArgs& a, hipStream_t st);
 hipError_t launch_pack_stem(int dtype, const PackArgs& a, hipStream_t st);
 hipError_t launch_copy2d(float* dst, long ldd, const float* src, long lds, int rows, int w, int accumulate, hipStream_t st);
+hipError_t launch_copy2d_multi(float* dst, long ldd, int ndst, long dstep, const float* src, long lds, int nsrc, long sstep, int rows, int w,
+                               hipStream_t st);
 hipError_t launch_unpack_grad(const float* g, float* out, int K, int C, int RS, hipStream_t st);
 // capi.cpp
 int fail(const char* fmt, ...);

@@ -246,6 +246,26 @@ __global__ __launch_bounds__(256) void copy2d_kernel(float* dst, long ldd, const
     *d = accumulate ? *d + v : v;
   }
 }
+// dst[j*dstep + r*ldd + c] = sum_i src[i*sstep + r*lds + c] for j < ndst, i < nsrc, left to right: the tile ([f, f, f],
+// [E, E]) and slice-sum (their gradients) forms of the single-branch head in ONE launch each instead of two or three
+__global__ __launch_bounds__(256) void copy2d_multi_kernel(float* dst, long ldd, int ndst, long dstep, const float* src, long lds, int nsrc,
+                                                           long sstep, int rows, int w) {
+  const long total = (long)rows * w;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / w, c = i - r * w;
+    float v = src[r * lds + c];
+    for (int s = 1; s < nsrc; ++s) v += src[s * sstep + r * lds + c];
+    for (int j = 0; j < ndst; ++j) dst[j * dstep + r * ldd + c] = v;
+  }
+}
+hipError_t launch_copy2d_multi(float* dst, long ldd, int ndst, long dstep, const float* src, long lds, int nsrc, long sstep, int rows, int w,
+                               hipStream_t st) {
+  long b = ((long)rows * w + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  hipLaunchKernelGGL(copy2d_multi_kernel, dim3((int)b), dim3(256), 0, st, dst, ldd, ndst, dstep, src, lds, nsrc, sstep, rows, w);
+  return hipGetLastError();
+}
 hipError_t launch_copy2d(float* dst, long ldd, const float* src, long lds, int rows, int w, int accumulate, hipStream_t st) {
   long b = ((long)rows * w + 255) / 256;
   if (b > 2048) b = 2048;
