@@ -66,3 +66,31 @@ def ssl_cr_grads(kind, p, x, y, u_s, logits_t, lambda_u, emulate):
         loss = F.cross_entropy(logits[:nx], y) + lambda_u * F.cross_entropy(logits[nx:], torch.softmax(logits_t, -1).max(-1)[1])
     loss.backward()
     return {k: v.grad.clone() for k, v in p.items()}, logits.detach(), float(loss.detach())
+
+
+def rsp_grads(p, i1, i2, i3, target, emulate):
+    """gradients of the RSP pre-training loss (pretrain_BreastPathQ.py:42-61: TripletNet -> Classifier -> CrossEntropyLoss)
+    w.r.t. every entry of `p`; three backbone passes with their OWN batch statistics (models/net.py:50-66)."""
+    for v in p.values():
+        v.grad = None
+    q = rnd if emulate else (lambda t: t)
+    e1, e2, e3 = (backbone_train(p, i, q) for i in (i1, i2, i3))
+    f = torch.cat((M.fc_head(p, torch.cat((e1, e2), 1)), M.fc_head(p, torch.cat((e2, e3), 1)), M.fc_head(p, torch.cat((e1, e3), 1))), 1)
+    logits = M.classifier_forward(p, f)
+    loss = F.cross_entropy(logits, target)
+    loss.backward()
+    return {k: v.grad.clone() for k, v in p.items()}, logits.detach(), float(loss.detach())
+
+
+def sup_grads(kind, p, x, y, emulate):
+    """gradients of the supervised fine-tuning loss (eval_Kather_SSL.py:51-79 / eval_Camelyon_SSL.py:52-98 'ce',
+    eval_BreastPathQ_SSL.py:52-84 'mse') w.r.t. every entry of `p` (TripletNet_Finetune de-triplicated)."""
+    for v in p.values():
+        v.grad = None
+    q = rnd if emulate else (lambda t: t)
+    e = backbone_train(p, x, q)
+    f = M.fc_head(p, torch.cat((e, e), 1))
+    logits = M.classifier_forward(p, torch.cat((f, f, f), 1))
+    loss = F.mse_loss(logits, y.view(-1, 1)) if kind == "mse" else F.cross_entropy(logits, y)
+    loss.backward()
+    return {k: v.grad.clone() for k, v in p.items()}, logits.detach(), float(loss.detach())

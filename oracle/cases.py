@@ -55,6 +55,27 @@ CASES = {
     "cam_sup": dict(script="cam_sup", hw=64, b=2, nb=2, modules=0, classes=2, lr=1e-3, wd=1e-4, opt="sgd"),
     # eval_BreastPathQ_SSL.train: supervised MSE, Adam (:396); image side is args.image_size (:58)
     "bpq_sup": dict(script="bpq_sup", hw=64, b=2, nb=2, modules=0, classes=1, lr=1e-3, wd=1e-4, opt="adam"),
+    # eval_Kather_SSL.train/validate (:32-99 / :102-151): supervised 9-class CE, Adam lr 1e-5 (:234,419), image side is
+    # args.image_size (:57).  96x96 is NOT 16-tileable past the stem (24/12/6/3 maps): the engine's fallback conv shapes
+    "kather_sup": dict(script="kather_sup", hw=96, b=2, nb=2, modules=0, classes=9, lr=1e-5, wd=1e-4, opt="adam"),
+    # BASELINE.json config 1 itself: --batch_size 32, 224x224, 9 classes -> [32,3,3,224,224] -> 96 images (56/28/14/7 maps);
+    # ONE iteration, reductions only (tests/golden/make_golden.py:gen_kather_sup_full)
+    "kather_sup_full": dict(script="kather_sup", hw=224, b=32, nb=1, modules=0, classes=9, lr=1e-5, wd=1e-4, opt="adam"),
+    # multi-iteration trajectories (bf16-fidelity yardstick): the reference's train() called once per iteration with ONE batch,
+    # same optimizer object throughout, 256x256, full fine-tune; per-iteration returned losses + final snapshot
+    "traj_bpq_cr": dict(script="bpq_cr", hw=256, b=2, mu=3, nb=1, iters=24, modules=0, classes=1, lr=1e-4, wd=1e-4,
+                        lambda_u=1.0, opt="adam"),
+    "traj_cam_cr": dict(script="cam_cr", hw=256, b=1, mu=3, nb=1, iters=24, modules=0, classes=2, lr=5e-4, wd=1e-4,
+                        lambda_u=1.0, opt="sgd"),
+    # checkpoint layouts (row f2): epoch 1 -> the reference's save dict -> torch.save -> fresh modules -> the reference's
+    # --resume / load code -> epoch 2.  Frozen backbones (--modules 62: fc.2 + the classifier train) keep the fixture small (only those tensors, the BatchNorm buffers and their optimizer state move).
+    "ckpt_bpq_cr": dict(script="bpq_cr", hw=256, b=1, mu=2, nb=2, modules=62, classes=1, lr=1e-4, wd=1e-4,
+                        lambda_u=1.0, opt="adam"),
+    "ckpt_cam_sup": dict(script="cam_sup", hw=64, b=2, nb=2, modules=62, classes=2, lr=1e-3, wd=1e-4, opt="sgd"),
+    # (one iteration per epoch, 128x128: with lr 0.01 SGD-Nesterov momentum and BatchNorm over a handful of values, ReLU-mask
+    # flips between two fp32 implementations get amplified by every further iteration -- measured 1e-5 -> 5e-2 over four
+    # iterations at 64x64 with torch-CPU fp32 itself showing the same flips against float64)
+    "ckpt_rsp": dict(script="rsp", hw=128, b=4, nb=1, classes=6, lr=0.01, wd=1e-4, opt="sgd"),
     # test_Camelyon16.test: forward-only WSI tile classification -> tumour-probability map ("next" row f3); the loader
     # yields (float32 RGB tile batch, x_mask, y_mask) for the tissue pixels of a mask, last batch ragged (:41-66)
     "cam_wsi": dict(script="cam_wsi", hw=64, b=4, classes=2, mask=(6, 5)),
@@ -87,6 +108,11 @@ def labeled_batches_kather(case, seed0=1000):
     c = CASES[case]
     return [(u8(seed0 + i, (c["b"], 3, 3, c["hw"], c["hw"])), ints(seed0 + 50 + i, (c["b"], 3), c["classes"]))
             for i in range(c["nb"])]
+
+
+def sup_batches_kather(case, seed0=1000):
+    """eval_Kather_SSL labeled loader (DatasetKather_Supervised_train, dataset.py): x u8 [b,3,3,H,W], y int64 [b,3]."""
+    return labeled_batches_kather(case, seed0)
 
 
 def val_batches_kather(case, seed0=4000):

@@ -137,3 +137,18 @@ def bpq_sup_train(p, b, opt, loader, image_size, faithful=True):
         losses.update(r["loss"], y.size(0))
         feats.append(r["feats"]); targets.append(y)
     return losses.avg, torch.cat(feats), torch.cat(targets)
+
+
+def kather_sup_train(p, b, opt, loader, image_size, faithful=True):
+    """eval_Kather_SSL.py:32-99 -> (loss_avg, acc_avg)."""
+    losses, acc = S.AverageMeter(), S.AverageMeter()
+    for x, y in loader:
+        x = x.float().reshape(-1, 3, image_size, image_size); y = y.long().reshape(-1)          # :54-57
+        r = S.supervised_step("ce", p, b, opt, x, y, faithful)
+        losses.update(r["loss"], y.size(0)); acc.update(r["acc"], y.size(0))
+    return losses.avg, acc.avg
+
+
+def kather_sup_validate(p, b, val_loader, faithful=True):
+    """eval_Kather_SSL.py:102-151 -> (loss_avg, acc_avg)."""
+    return kather_cr_validate(p, b, val_loader, faithful)

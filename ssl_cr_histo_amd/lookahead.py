@@ -26,10 +26,22 @@ class Lookahead:
         self._net = None
 
     def bind(self, model, classifier):
-        """tell the wrapper which (model, classifier) pair the inner optimizer updates."""
+        """optional: name the (model, classifier) pair the inner optimizer updates.  Not needed at the reference's call site
+        (``scheduler = Lookahead(optimizer, la_steps=5, la_alpha=0.5)``, pretrain_BreastPathQ.py:247): step() finds the engine
+        binding that train() made for exactly this optimizer's parameters."""
         eng = get_engine(next(model.parameters()).device)
         self._net = eng.bind(model, classifier)
         return self
+
+    def _find_net(self):
+        params = [p for g in self.optimizer.param_groups for p in g["params"]]
+        ids = {id(p) for p in params}
+        eng = get_engine(params[0].device)
+        for net in eng._bound.values():
+            if net.still_valid() and {id(p) for p in net.params if p.requires_grad} == ids:
+                return net
+        raise RuntimeError("Lookahead.step(): no engine binding holds this optimizer's parameters yet -- the reference calls it "
+                           "after train() (pretrain_BreastPathQ.py:286-293); or name the modules with .bind(model, classifier)")
 
     @property
     def param_groups(self):
@@ -48,8 +60,8 @@ class Lookahead:
         self.optimizer.load_state_dict(state_dict)
 
     def step(self, closure=None):
-        if self._net is None:
-            raise RuntimeError("Lookahead.bind(model, classifier) must be called before step()")
+        if self._net is None or not self._net.still_valid():
+            self._net = self._find_net()
         self._net.optimizer_step(self.optimizer)
         self._la_step += 1
         if self._la_step >= self._total_la_steps:

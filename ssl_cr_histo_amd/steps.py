@@ -11,7 +11,7 @@ eval_Kather_SSL_CR.train/validate           kather_cr_train / kather_cr_validate
 pretrain_BreastPathQ|Camelyon16|RSP.train   rsp_train / rsp_validate            (:27-92 / :95-148)
 eval_Camelyon_SSL.train                     cam_sup_train                       (:31-119)
 eval_BreastPathQ_SSL.train                  bpq_sup_train                       (:35-103)
-eval_Kather_SSL.train                       kather_sup_train                    (:32-99)
+eval_Kather_SSL.train/validate              kather_sup_train / kather_sup_validate (:32-99 / :102-151)
 """
 import time
 
@@ -301,7 +301,9 @@ def bpq_sup_train(args, model, classifier, train_loader, criterion, optimizer, e
 
 
 def kather_sup_train(args, model, classifier, train_loader, criterion, optimizer, epoch):
-    """eval_Kather_SSL.train (:32-99; the reference file does not parse, :243): student-only CE -> (loss, acc)."""
+    """eval_Kather_SSL.train (:32-99; the reference file does not parse as a whole, :243): student-only CE -> (loss, acc)."""
+    if criterion is not None and not isinstance(criterion, torch.nn.CrossEntropyLoss):
+        raise NotImplementedError("the reference fine-tunes Kather with nn.CrossEntropyLoss (eval_Kather_SSL.py:410)")
     eng = get_engine(_device_of(model))
     model.train()
     classifier.train()
@@ -315,6 +317,13 @@ def kather_sup_train(args, model, classifier, train_loader, criterion, optimizer
         meters.add(r["losses"], y.size(0))
     m = meters.meters()
     return m["loss"].avg, m["acc"].avg
+
+
+def kather_sup_validate(args, model, classifier, val_loader, criterion, epoch):
+    """eval_Kather_SSL.validate (:102-151) -> (loss_avg, acc_avg): eval-mode forward + CE + accuracy."""
+    if criterion is not None and not isinstance(criterion, torch.nn.CrossEntropyLoss):
+        raise NotImplementedError("the reference validates Kather with nn.CrossEntropyLoss")
+    return kather_cr_validate(args, model, classifier, val_loader, epoch)
 
 
 # ------------------------------------------------------------------------------------------------ WSI inference (f3)

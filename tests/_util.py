@@ -74,3 +74,75 @@ def rel_err(a, b):
     a = torch.as_tensor(a).double()
     b = torch.as_tensor(b).double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+# ---------------------------------------------------------------- reference-written checkpoints (row f2)
+def ckpt_tree(obj, path=""):
+    """the same JSON-able description tests/golden/make_golden.py:tree_struct stores for the reference-written file."""
+    import argparse
+    if isinstance(obj, argparse.Namespace):
+        return {"t": "ns", "v": ckpt_tree(vars(obj), path)}
+    if isinstance(obj, dict):
+        return {"t": "dict", "od": type(obj).__name__,
+                "k": [[["i", k] if isinstance(k, int) else ["s", k], ckpt_tree(v, f"{path}/{k}")] for k, v in obj.items()]}
+    if isinstance(obj, (list, tuple)):
+        return {"t": "list" if isinstance(obj, list) else "tuple", "v": [ckpt_tree(v, f"{path}/{i}") for i, v in enumerate(obj)]}
+    if torch.is_tensor(obj):
+        return {"t": "tensor", "dtype": str(obj.dtype).replace("torch.", ""), "shape": list(obj.shape), "path": path}
+    if obj is None or isinstance(obj, (bool, int, float, str)):
+        return {"t": "py", "type": type(obj).__name__, "v": obj}
+    raise TypeError(f"unexpected object in a checkpoint at {path}: {type(obj)}")
+
+
+def strip_values(tree):
+    """structure only: drop python scalar values (losses, epoch) so that two runs' files compare by shape of the pickle."""
+    if tree["t"] == "py":
+        return {"t": "py", "type": tree["type"]}
+    if tree["t"] == "ns":
+        return {"t": "ns", "v": strip_values(tree["v"])}
+    if tree["t"] == "dict":
+        return {"t": "dict", "od": tree["od"], "k": [[k, strip_values(v)] for k, v in tree["k"]]}
+    if tree["t"] in ("list", "tuple"):
+        return {"t": tree["t"], "v": [strip_values(v) for v in tree["v"]]}
+    return tree
+
+
+def rebuild_ckpt(name, init_by_sub):
+    """The checkpoint dict the REFERENCE wrote in make_golden.py, rebuilt leaf by leaf: structure, key order and python scalars
+    from ``ckpt_tree``; tensors from the fixture (or its alias table), else from the seeded initial state_dict of that
+    sub-dict (``init_by_sub``: {'model_student': (state_dict, has_module_prefix), ...})."""
+    import argparse
+    import json
+    g = load_golden(name)
+    tree = json.loads(str(g[f"{name}/ckpt_tree"]))
+    alias = json.loads(str(g[f"{name}/ckpt_alias"]))
+    assert bool(g[f"{name}/ckpt_has_values"]), "this fixture carries the structure of the file only"
+
+    def tensor(node):
+        path = alias.get(node["path"], node["path"])
+        key = f"{name}/ckpt{path}"
+        if key in g.files:
+            t = torch.from_numpy(g[key])
+        else:
+            _, sub, k = node["path"].split("/", 2)
+            sd, dp = init_by_sub[sub]
+            t = sd[k[7:] if dp else k].clone()
+        assert str(t.dtype).replace("torch.", "") == node["dtype"] and list(t.shape) == node["shape"], node
+        return t
+
+    def build(node):
+        if node["t"] == "ns":
+            return argparse.Namespace(**build(node["v"]))
+        if node["t"] == "dict":
+            d = OrderedDict() if node["od"] == "OrderedDict" else {}
+            for (kt, k), v in node["k"]:
+                d[int(k) if kt == "i" else k] = build(v)
+            return d
+        if node["t"] == "list":
+            return [build(v) for v in node["v"]]
+        if node["t"] == "tuple":
+            return tuple(build(v) for v in node["v"])
+        if node["t"] == "tensor":
+            return tensor(node)
+        return node["v"]
+    return build(tree), tree

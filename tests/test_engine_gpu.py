@@ -259,9 +259,9 @@ def test_cam_cr_full_size_step_vs_reference(dtype):
     torch.randperm shuffles) at the size of the benchmark workload -- student 640 / teacher 448 images of 256x256 -- against
     reductions of the reference's own iteration: loss averages and accuracy, feature row norms / column sums, post-step
     snapshot, and every parameter gradient (norm + seeded +-1 projection of the reference's .grad; the engine keeps the
-    gradients of the last backward, read here after the epoch function returned).  fp32: 1e-3 on losses/features, 5e-3 / 2e-2
-    per gradient norm / projection (two fp32 runs, cf. the float64 yardstick of the BreastPathQ full-size case);
-    bf16: 6e-2 on losses, 0.2 on features, gradient norms within 0.35."""
+    gradients of the last backward, read here after the epoch function returned), against the float64 run of the same iteration.
+    fp32: 1e-3 on losses/features, gradients within max(3e-3, 3 x the reference's own fp32 error); bf16: 6e-2 on losses, 0.2 on
+    features, gradients within 2 x / 3.5 x the emulated bf16-storage error + 0.05."""
     from ssl_cr_histo_amd import steps
     eng = _engine(dtype)
     name = "cam_cr_full"
@@ -293,17 +293,23 @@ def test_cam_cr_full_size_step_vs_reference(dtype):
     st = eng.bind(ms, cs)                      # the cached binding of the epoch function: gradients of its last backward
     names = [str(n) for n in g[f"{name}/grad_names"]]
     assert names == [k for k, _ in list(ms.named_parameters()) + list(cs.named_parameters())]
-    l2_ref, pr_ref = g[f"{name}/grad_l2"], g[f"{name}/grad_probe"]
-    tol_l2, tol_pr = (5e-3, 2e-2) if dtype == "fp32" else (0.35, 1.5)
+    # against the FLOAT64 run of the same iteration (same shuffles), like the BreastPathQ full-size case: fp32 within
+    # max(3e-3, 3 x the reference's own fp32 error); bf16 within 2 x (norm) / 3.5 x (one +-1 projection) the error that bf16
+    # storage alone causes in the CPU emulation of this iteration (oracle/bf16_emul.py) + 0.05
+    l2_ref, pr_ref, ref_err, emu = g[f"{name}/grad_l2_f64"], g[f"{name}/grad_probe_f64"], g[f"{name}/grad_ref32_err"], g[f"{name}/grad_bf16emul_err"]
     rows, bad = [], []
     for i, k in enumerate(names):
         gr = st.grad(i).cpu().double().reshape(-1)
         e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
         e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
-        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}")
+        tol_l2 = tol_pr = max(3e-3, 3.0 * ref_err[i])
+        if dtype == "bf16":
+            tol_l2, tol_pr = 2.0 * emu[i] + 0.05, 3.5 * emu[i] + 0.05
+        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}  "
+                    f"(reference fp32: {ref_err[i]:.2e}, bf16 emulation: {emu[i]:.2e})")
         if e_l2 > tol_l2 or e_pr > tol_pr:
             bad.append(rows[-1])
-    print(f"[{dtype}] Camelyon full-size gradients vs the reference's .grad:\n" + "\n".join(rows))
+    print(f"[{dtype}] Camelyon full-size gradients vs the float64 run of the same iteration:\n" + "\n".join(rows))
     assert not bad, "\n".join(bad)
 
 
@@ -343,7 +349,7 @@ def test_rsp_epoch_and_lookahead_vs_reference(dtype):
     model, cls = build("triplet", "mlp", 6, False)
     opt = torch.optim.SGD(list(model.parameters()) + list(cls.parameters()), lr=c["lr"], momentum=0.9, weight_decay=c["wd"],
                           nesterov=True)
-    la = Lookahead(opt, la_steps=5, la_alpha=0.5).bind(model, cls)
+    la = Lookahead(opt, la_steps=5, la_alpha=0.5)               # the reference's call site, pretrain_BreastPathQ.py:247
     a = ns(tile_h=c["hw"], tile_w=c["hw"])
     ret = steps.rsp_train(a, model, cls, C.rsp_batches(name), torch.nn.CrossEntropyLoss(), opt, 1)
     ts, tf, tp = TOLS[dtype]
@@ -367,9 +373,9 @@ def test_rsp_full_size_step_vs_reference(dtype):
     """One RSP pre-training iteration at the reference's default size (pretrain_BreastPathQ.py --batch_size 128: 3 x 128
     images of 256x256 through the shared TripletNet backbone, 6-way CE, SGD-Nesterov) against reductions of the reference's
     own iteration: loss / accuracy, feature row norms and column sums, post-step snapshot, and every parameter gradient
-    through its L2 norm and a seeded +-1 projection of the reference's .grad.  fp32: 1e-3 on loss/features, 5e-3 / 2e-2 per
-    gradient norm / projection (two fp32 implementations at this size, cf. the float64 yardstick of the SSL_CR full-size case);
-    bf16: 6e-2 on loss, 0.2 on features, gradient norms within 0.35 (storage noise, see oracle/bf16_emul.py)."""
+    through its L2 norm and a seeded +-1 projection, against the float64 run of the same iteration.  fp32: 1e-3 on loss/features,
+    gradients within max(3e-3, 3 x the reference's own fp32 error); bf16: 6e-2 on loss, 0.2 on features, gradients within
+    2 x / 3.5 x the emulated bf16-storage error + 0.05 (oracle/bf16_emul.py)."""
     from ssl_cr_histo_amd import steps
     eng = _engine(dtype)
     name = "rsp_full"
@@ -403,18 +409,22 @@ def test_rsp_full_size_step_vs_reference(dtype):
     names = [str(n) for n in g[f"{name}/grad_names"]]
     mine = [k for k, _ in list(model.named_parameters()) + list(cls.named_parameters())]
     assert names == mine
-    l2_ref, pr_ref = g[f"{name}/grad_l2"], g[f"{name}/grad_probe"]
-    # fp32: norm 5e-3, projection 2e-2 (two fp32 runs, each ~4e-3 from the exact gradient at this size; a projection is ~3 sigma)
-    tol_l2, tol_pr = (5e-3, 2e-2) if dtype == "fp32" else (0.35, 1.5)
+    # against the FLOAT64 run of the same iteration: fp32 within max(3e-3, 3 x the reference's own fp32 error); bf16 within
+    # 2 x / 3.5 x the emulated bf16-storage error + 0.05 (norm / one +-1 projection) -- the rule of the SSL_CR full-size cases
+    l2_ref, pr_ref, ref_err, emu = g[f"{name}/grad_l2_f64"], g[f"{name}/grad_probe_f64"], g[f"{name}/grad_ref32_err"], g[f"{name}/grad_bf16emul_err"]
     rows, bad = [], []
     for i, k in enumerate(names):
         gr = net_.grad(i).cpu().double().reshape(-1)
         e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
         e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
-        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}")
+        tol_l2 = tol_pr = max(3e-3, 3.0 * ref_err[i])
+        if dtype == "bf16":
+            tol_l2, tol_pr = 2.0 * emu[i] + 0.05, 3.5 * emu[i] + 0.05
+        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}  "
+                    f"(reference fp32: {ref_err[i]:.2e}, bf16 emulation: {emu[i]:.2e})")
         if e_l2 > tol_l2 or e_pr > tol_pr:
             bad.append(rows[-1])
-    print(f"[{dtype}] RSP full-size gradients vs the reference's .grad:\n" + "\n".join(rows))
+    print(f"[{dtype}] RSP full-size gradients vs the float64 run of the same iteration:\n" + "\n".join(rows))
     assert not bad, "\n".join(bad)
 
 

@@ -1,0 +1,327 @@
+"""Round-2 step-level parity on the MI355X (through the C-ABI): BASELINE config 1 (Kather supervised, 224x224, 9 classes), the
+EMA teacher against the oracle, reference-layout checkpoints (row f2: read the reference's file, continue like the reference),
+multi-iteration trajectories (bf16 fidelity as a bounded, measured quantity), virtual-rank sharding."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cases as C  # noqa: E402
+from oracle import model as OM  # noqa: E402
+from oracle import steps as S  # noqa: E402
+
+from _util import check_snapshot, load_golden, merged, oracle_state, rebuild_ckpt, rel_err  # noqa: E402
+from test_engine_gpu import DEV, TOLS, _engine, build, freeze, ns, state_of  # noqa: E402
+
+
+def _grad_table(tag, st, names, l2_ref, pr_ref, tol_fn):
+    rows, bad = [], []
+    for i, k in enumerate(names):
+        gr = st.grad(i).cpu().double().reshape(-1)
+        e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
+        e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
+        tol_l2, tol_pr = tol_fn(i)
+        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e} (<= {tol_l2:.1e})  projection err/|g| {e_pr:.2e} (<= {tol_pr:.1e})")
+        if e_l2 > tol_l2 or e_pr > tol_pr:
+            bad.append(rows[-1])
+    print(tag + "\n" + "\n".join(rows))
+    assert not bad, "\n".join(bad)
+
+
+# ------------------------------------------------------------------------------------------------ config 1: Kather supervised
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_kather_supervised_epoch_vs_reference(dtype):
+    """eval_Kather_SSL.train / validate (golden from the reference file's own functions) at 96x96: after the stem the maps are
+    24/12/6/3 pixels -- none of them 16-tileable, so every conv runs on the engine's generic shapes."""
+    from ssl_cr_histo_amd import steps
+    _engine(dtype)
+    name = "kather_sup"
+    c = C.CASES[name]
+    g = load_golden(name)
+    ms, cs = build("finetune", "finetune", c["classes"], False)
+    opt = torch.optim.Adam(list(ms.parameters()) + list(cs.parameters()), lr=c["lr"], betas=(0.9, 0.999), weight_decay=c["wd"])
+    crit = torch.nn.CrossEntropyLoss()
+    ret = steps.kather_sup_train(ns(image_size=c["hw"]), ms, cs, C.sup_batches_kather(name), crit, opt, 1)
+    ts, tf, tp = TOLS[dtype]
+    assert abs(ret[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0], (ret[0], g[f"{name}/ret"][0])
+    if dtype == "fp32":
+        assert ret[1] == g[f"{name}/ret"][1]
+        check_snapshot(g, name, state_of(ms, cs), tp)
+    val = steps.kather_sup_validate(ns(), ms, cs, C.val_batches_kather(name), crit, 1)
+    assert abs(val[0] - g[f"{name}/val"][0]) <= (5e-3 if dtype == "fp32" else 1e-1) * g[f"{name}/val"][0]
+    if dtype == "fp32":
+        assert val[1] == g[f"{name}/val"][1]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_kather_config1_full_size_step_vs_reference(dtype):
+    """BASELINE.json config 1 itself: ONE iteration of eval_Kather_SSL.train at --batch_size 32, 224x224, 9 classes (96 images;
+    56/28/14/7 maps), Adam lr 1e-5 -- loss/accuracy, post-step snapshot, validate(), and every parameter gradient against the
+    float64 run of the same iteration (fp32: max(3e-3, 3 x the reference's own fp32 error); bf16: 2 x / 3.5 x the emulated
+    bf16-storage error + 0.05 for norm / projection -- the rule of the BreastPathQ full-size case)."""
+    from ssl_cr_histo_amd import steps
+    eng = _engine(dtype)
+    name = "kather_sup_full"
+    c = C.CASES[name]
+    g = load_golden(name)
+    ms, cs = build("finetune", "finetune", c["classes"], False)
+    opt = torch.optim.Adam(list(ms.parameters()) + list(cs.parameters()), lr=c["lr"], betas=(0.9, 0.999), weight_decay=c["wd"])
+    crit = torch.nn.CrossEntropyLoss()
+    ret = steps.kather_sup_train(ns(image_size=c["hw"]), ms, cs, C.sup_batches_kather(name), crit, opt, 1)
+    ts, tf, tp = TOLS[dtype]
+    assert abs(ret[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0], (ret[0], g[f"{name}/ret"][0])
+    assert abs(ret[1] - g[f"{name}/ret"][1]) <= (1.0 if dtype == "fp32" else 3.0) / 96 + 1e-9
+    if dtype == "fp32":
+        check_snapshot(g, name, state_of(ms, cs), tp)
+    st = eng.bind(ms, cs)                      # the epoch function's binding: gradients of its (only) backward
+    names = [str(n) for n in g[f"{name}/grad_names"]]
+    assert names == [k for k, _ in list(ms.named_parameters()) + list(cs.named_parameters())]
+    ref_err, emu = g[f"{name}/grad_ref32_err"], g[f"{name}/grad_bf16emul_err"]
+
+    def tol(i):
+        if dtype == "fp32":
+            t = max(3e-3, 3.0 * ref_err[i])
+            return t, t
+        return 2.0 * emu[i] + 0.05, 3.5 * emu[i] + 0.05
+    _grad_table(f"[{dtype}] config-1 gradients vs the float64 run of the same iteration:", st, names, g[f"{name}/grad_l2_f64"],
+                g[f"{name}/grad_probe_f64"], tol)
+    val = steps.kather_sup_validate(ns(), ms, cs, C.val_batches_kather(name), crit, 1)
+    assert abs(val[0] - g[f"{name}/val"][0]) <= (5e-3 if dtype == "fp32" else 1e-1) * g[f"{name}/val"][0]
+
+
+# ------------------------------------------------------------------------------------------------ a11: EMA teacher
+@pytest.mark.parametrize("decay", [0.99, 0.5, 0.0])
+def test_ema_teacher_vs_oracle(decay):
+    """north_star's EMA teacher: teacher <- decay * teacher + (1 - decay) * student on every parameter, BatchNorm buffers copied
+    (decay 0 == the reference's copy.deepcopy, eval_BreastPathQ_SSL_CR.py:515-516) -- against oracle/steps.py:teacher_refresh, and
+    the refreshed teacher's eval forward against the oracle's forward with the oracle's refreshed state."""
+    from ssl_cr_histo_amd import steps
+    _engine("fp32")
+    mt, ct = build("finetune", "finetune", 2, True, seed=7)
+    ms, cs = build("finetune", "finetune", 2, True, seed=C.PARAM_SEED)
+    with torch.no_grad():                                        # a student that has trained: counters differ from the teacher's
+        for b in ms.model.bn_modules():
+            b.num_batches_tracked += 9
+
+    def oracle_of(seed):
+        sd = OM.init_state(seed, OM.net_param_specs(), random_running_stats=True)
+        csd = OM.init_state(seed + 1, OM.classifier_param_specs("finetune", 2))
+        p, b = OM.split_state(sd)
+        pc, _ = OM.split_state(csd)
+        return merged(p, pc), b
+    pt, bt = oracle_of(7)
+    ps, bs = oracle_of(C.PARAM_SEED)
+    for k in bs:
+        if k.endswith("num_batches_tracked"):
+            bs[k] = bs[k] + 9
+    S.teacher_refresh(ps, bs, pt, bt, decay)
+    steps.teacher_refresh(mt, ct, ms, cs, decay)
+    torch.cuda.synchronize()
+    got = state_of(mt, ct)
+    for k, v in list(pt.items()) + list(bt.items()):
+        if k.endswith("num_batches_tracked"):
+            assert int(got[k]) == int(v), k
+        else:
+            assert torch.allclose(got[k], v.detach(), rtol=2e-6, atol=1e-7), (k, float((got[k] - v.detach()).abs().max()))
+    x = C.u8(8100, (3, 3, 64, 64))
+    mt.eval(); ct.eval()
+    logits = ct(mt(x.to(DEV)))
+    with torch.no_grad():
+        want = OM.classifier_forward(pt, OM.finetune_forward(pt, bt, x.float(), False, False))
+    assert rel_err(logits.cpu(), want) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ f2: reference checkpoints
+def _opt_for(c, ms, cs):
+    prm = filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters()))
+    if c["opt"] == "adam":
+        return torch.optim.Adam(prm, lr=c["lr"], betas=(0.9, 0.999), weight_decay=c["wd"])
+    return torch.optim.SGD(prm, lr=c["lr"], momentum=0.9, weight_decay=c["wd"], nesterov=True)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("source", ["reference_file", "own_file"])
+def test_checkpoint_ssl_cr_resume_continues_like_the_reference(source, dtype, tmp_path):
+    """eval_BreastPathQ_SSL_CR layout.  'reference_file': the .pt the REFERENCE wrote after its epoch 1 (rebuilt from the fixture)
+    is resumed through ssl_cr_histo_amd.checkpoint and epoch 2 must equal the reference's own continued run.  'own_file': epoch 1
+    on the engine, teacher refresh, save in the reference's layout, resume into fresh modules, epoch 2 -- same golden."""
+    from ssl_cr_histo_amd import checkpoint as CK, steps
+    _engine(dtype)
+    name = "ckpt_bpq_cr"
+    c = C.CASES[name]
+    g = load_golden(name)
+    ts, tf, tp = TOLS[dtype]
+
+    def fresh():
+        mt, ct = build("finetune", "finetune", 1, True)
+        ms, cs = build("finetune", "finetune", 1, True)
+        freeze(mt, 64)
+        freeze(ms, c["modules"])
+        return mt, ct, ms, cs, _opt_for(c, ms, cs)
+    f = str(tmp_path / "fine_CR_trained_model_1.pt")
+    a = ns(lambda_u=c["lambda_u"])
+    if source == "reference_file":
+        sd0 = OM.init_state(C.PARAM_SEED, OM.net_param_specs(), random_running_stats=True)
+        cd0 = OM.init_state(C.PARAM_SEED + 1, OM.classifier_param_specs("finetune", 1))
+        ref, _ = rebuild_ckpt(name, {"model_student": (sd0, False), "model_teacher": (sd0, False),
+                                     "classifier_student": (cd0, False), "classifier_teacher": (cd0, False)})
+        torch.save(ref, f)
+    else:
+        mt, ct, ms, cs, opt = fresh()
+        r1 = steps.bpq_cr_train(a, mt, ms, ct, cs, C.labeled_batches(name), C.unlabeled_batches(name), opt, 1)
+        for i in range(3):
+            assert abs(r1[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i])
+        mt, ct = copy.deepcopy(ms), copy.deepcopy(cs)                                   # :515-516
+        CK.save_ssl_cr(f, None, ms, mt, ct, cs, opt, 1, r1[0], r1[1], r1[2])
+    mt, ct, ms, cs, opt = fresh()
+    start, _ = CK.resume(f, opt, map_location=DEV, model_student=ms, model_teacher=mt, classifier_teacher=ct, classifier_student=cs)
+    assert start == 2
+    r2 = steps.bpq_cr_train(a, mt, ms, ct, cs, C.labeled_batches(name, 1200), C.unlabeled_batches(name, 2200), opt, start)
+    for i in range(3):
+        assert abs(r2[i] - g[f"{name}/ret2"][i]) <= ts * abs(g[f"{name}/ret2"][i]), (i, r2[i], g[f"{name}/ret2"][i])
+    assert rel_err(r2[3].cpu(), g[f"{name}/feats2"]) < tf
+    if dtype == "fp32":
+        check_snapshot(g, name + "/e2", state_of(ms, cs), tp)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_checkpoint_finetune_resume_and_ssl_cr_start(dtype, tmp_path):
+    """eval_Camelyon_SSL layout with DataParallel keys, as the reference wrote it: --resume -> epoch 2 equals the reference's; and the
+    SSL_CR scripts' way in (teacher + student from 'model' / 'classifier', module. stripped) gives working nets."""
+    from ssl_cr_histo_amd import checkpoint as CK, steps
+    _engine(dtype)
+    name = "ckpt_cam_sup"
+    c = C.CASES[name]
+    g = load_golden(name)
+    ts, tf, tp = TOLS[dtype]
+    sd0 = OM.init_state(C.PARAM_SEED, OM.net_param_specs())
+    cd0 = OM.init_state(C.PARAM_SEED + 1, OM.classifier_param_specs("finetune", 2))
+    ref, _ = rebuild_ckpt(name, {"model": (sd0, True), "classifier": (cd0, True)})
+    f = str(tmp_path / "fine_tuned_model_1.pt")
+    torch.save(ref, f)
+    ms, cs = build("finetune", "finetune", 2, False)
+    freeze(ms, c["modules"])
+    opt = _opt_for(c, ms, cs)
+    msw, csw = torch.nn.DataParallel(ms), torch.nn.DataParallel(cs)               # eval_Camelyon_SSL.py:355-356
+    start, _ = CK.resume(f, opt, map_location=DEV, model=msw, classifier=csw)
+    torch.manual_seed(782)
+    r2 = steps.cam_sup_train(ns(image_size=c["hw"]), msw, csw, C.labeled_batches_cls(name, 1200, 1), C.labeled_batches_cls(name, 1300, 0),
+                             opt, start)
+    assert abs(r2[0] - g[f"{name}/ret2"][0]) <= ts * g[f"{name}/ret2"][0]
+    assert rel_err(r2[2].cpu(), g[f"{name}/feats2"]) < tf
+    if dtype == "fp32":
+        assert r2[1] == g[f"{name}/ret2"][1]
+        check_snapshot(g, name + "/e2", state_of(ms, cs), tp)
+    mt, ct = build("finetune", "finetune", 2, True, seed=3)
+    m2, c2 = build("finetune", "finetune", 2, True, seed=4)
+    CK.load_finetuned(f, (mt, m2), (ct, c2), map_location=DEV)
+    x = C.u8(8200, (2, 3, 64, 64)).to(DEV)
+    mt.eval(); m2.eval()
+    assert torch.equal(mt(x), m2(x))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_checkpoint_pretrain_resume_continues_like_the_reference(dtype, tmp_path):
+    """pretrain_BreastPathQ layout: epoch 1 + the per-epoch Lookahead 'scheduler.step()' on the engine, saved as the reference saves
+    it ('model' + 'optimizer', DataParallel keys, no classifier), --resume into fresh modules (classifier back at its seeded
+    initialisation, like a fresh reference process), epoch 2 against the reference's own resumed run."""
+    from ssl_cr_histo_amd import checkpoint as CK, steps
+    from ssl_cr_histo_amd.lookahead import Lookahead
+    _engine(dtype)
+    name = "ckpt_rsp"
+    c = C.CASES[name]
+    g = load_golden(name)
+    ts, tf, tp = TOLS[dtype]
+
+    def fresh():
+        model, cls = build("triplet", "mlp", 6, False)
+        opt = torch.optim.SGD(list(model.parameters()) + list(cls.parameters()), lr=c["lr"], momentum=0.9, weight_decay=c["wd"], nesterov=True)
+        return model, cls, opt, Lookahead(opt, la_steps=5, la_alpha=0.5)
+    model, cls, opt, sched = fresh()
+    a = ns(tile_h=c["hw"], tile_w=c["hw"])
+    crit = torch.nn.CrossEntropyLoss()
+    r1 = steps.rsp_train(a, model, cls, C.rsp_batches(name), crit, opt, 1)
+    sched.step()                                                                   # pretrain_BreastPathQ.py:293
+    assert abs(r1[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0]
+    if dtype == "fp32":
+        check_snapshot(g, name + "/e1", state_of(model, cls), 2e-2)
+    f = str(tmp_path / "model_1.pt")
+    CK.save_pretrain(f, None, model, sched, 1, r1[0], r1[1], data_parallel_keys=True)
+    model, cls, opt, sched = fresh()
+    start, ck = CK.resume(f, opt, map_location=DEV, model=model)
+    assert start == 2 and "classifier" not in ck
+    r2 = steps.rsp_train(a, model, cls, C.rsp_batches(name, 3200), crit, opt, start)
+    if dtype == "fp32":
+        # this run amplifies fp32 round-off (lr 0.01 SGD-Nesterov, stale-gradient Lookahead step, BatchNorm over 16-element maps):
+        # the golden's float64 run says how far the REFERENCE's own fp32 epoch-2 features are from the exact ones (several
+        # percent); the engine is held to twice that distance, against float64
+        ref_err = float(g[f"{name}/feats2_ref32_err"][0])
+        assert abs(r2[0] - g[f"{name}/ret2"][0]) <= 5e-3 * g[f"{name}/ret2"][0], (r2[0], g[f"{name}/ret2"][0])
+        assert abs(r2[0] - g[f"{name}/ret2_f64"][0]) <= 5e-3 * g[f"{name}/ret2_f64"][0]
+        e = rel_err(r2[2].cpu(), g[f"{name}/feats2_f64"])
+        print(f"epoch-2 features vs float64: engine {e:.3e}, reference fp32 {ref_err:.3e}")
+        assert e <= max(2e-3, 2.0 * ref_err), (e, ref_err)
+        check_snapshot(g, name + "/e2", state_of(model, cls), 2e-2)
+    else:
+        assert abs(r2[0] - g[f"{name}/ret2"][0]) <= 0.15 * g[f"{name}/ret2"][0]
+
+
+# ------------------------------------------------------------------------------------------------ trajectories (bf16 fidelity)
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["traj_bpq_cr", "traj_cam_cr"])
+def test_trajectory_vs_reference(name, dtype):
+    """12 consecutive iterations of the reference's own train() (one call per iteration, one optimizer object, 256x256, full
+    fine-tune; Adam / MSE for BreastPathQ, SGD-Nesterov / CE + pseudo-label CE for Camelyon), per-iteration returned losses,
+    validate() every 4 iterations, final snapshot.  fp32 mode is held to the north-star 1e-3 on EVERY iteration's losses.
+    bf16 mode (the mode the throughput is quoted in) is measured: its per-iteration deviation is printed and must stay inside
+    6e-2 WITHOUT growing -- the mean deviation of the last four iterations may not exceed twice that of the first four (+0.5 %):
+    bf16 storage noise perturbs each step, it does not accumulate into a different training run."""
+    from ssl_cr_histo_amd import steps
+    _engine(dtype)
+    c = C.CASES[name]
+    g = load_golden(name)
+    cam = c["script"] == "cam_cr"
+    mt, ct = build("finetune", "finetune", c["classes"], True)
+    ms, cs = build("finetune", "finetune", c["classes"], True)
+    freeze(mt, 64)
+    freeze(ms, c["modules"])
+    opt = _opt_for(c, ms, cs)
+    want, wvals = g[f"{name}/ret"], g[f"{name}/vals"]
+    dev, vdev = [], []
+    torch.manual_seed(780)
+    for it in range(c["iters"]):
+        if cam:
+            r = steps.cam_cr_train(ns(lambda_u=c["lambda_u"], image_size=c["hw"]), mt, ms, ct, cs,
+                                   C.labeled_batches_cls(name, 1000 + 7 * it, 1), C.labeled_batches_cls(name, 1100 + 7 * it, 0),
+                                   C.unlabeled_batches(name, 2000 + 7 * it), C.unlabeled_batches(name, 2100 + 7 * it), opt, 1)
+        else:
+            r = steps.bpq_cr_train(ns(lambda_u=c["lambda_u"]), mt, ms, ct, cs, C.labeled_batches(name, 1000 + 7 * it),
+                                   C.unlabeled_batches(name, 2000 + 7 * it), opt, 1)
+        dev.append(max(abs(r[i] - want[it][i]) / abs(want[it][i]) for i in range(3)))
+        if cam and dtype == "fp32":
+            assert abs(r[3] - want[it][3]) <= 1.0 / 6 + 1e-9, (it, r[3], want[it][3])       # accuracy over 6 labeled images
+        if (it + 1) % 4 == 0:
+            if cam:
+                v = steps.cam_cr_validate(ns(), ms, cs, C.val_batches_cls(name, 4000, 1), C.val_batches_cls(name, 4100, 0), 1)
+            else:
+                v = (steps.bpq_cr_validate(ns(), ms, cs, C.val_batches_reg(name), 1),)
+            vdev.append(abs(v[0] - wvals[len(vdev)][0]) / abs(wvals[len(vdev)][0]))
+    print(f"[{dtype}] {name}: per-iteration max relative loss deviation from the reference:\n   " + " ".join(f"{d:.2e}" for d in dev) +
+          "\n   validate() after 4/8/12 iterations: " + " ".join(f"{d:.2e}" for d in vdev))
+    if dtype == "fp32":
+        assert max(dev) <= 1e-3, dev
+        assert max(vdev) <= 5e-3, vdev
+        # 2e-2 on the state: a conv weight in front of a BatchNorm has directions the loss does not depend on (scale, per-channel
+        # offset); their true gradient is zero, what two fp32 implementations compute there is round-off of opposite sign, and
+        # Adam turns any nonzero gradient into a step of size lr -- so pre-BatchNorm means (running_mean) drift apart by ~lr per
+        # iteration while losses, features and validate() stay within 1e-3 (measured: 1e-2 on layer4.1.bn2.running_mean)
+        check_snapshot(g, name, state_of(ms, cs), 2e-2)
+    else:
+        assert max(dev) <= 6e-2, dev
+        head, tail = float(np.mean(dev[:4])), float(np.mean(dev[-4:]))
+        assert tail <= 2.0 * head + 5e-3, (head, tail, dev)
+        assert max(vdev) <= 0.15, vdev

@@ -167,3 +167,58 @@ def test_stage_activations(mode):
                   "model.layer4.1.bn2.running_var"):
             assert rel_err(bn2[k], g[f"stages/train/{k}"]) < 1e-5, k
         assert int(bn2["model.bn1.num_batches_tracked"]) == int(g["stages/train/nbt"]) == 3
+
+
+def test_kather_supervised():
+    """config 1's script, eval_Kather_SSL.train/validate (the slice of the reference file above ``def parse_args``), 96x96."""
+    name = "kather_sup"
+    c = C.CASES[name]
+    g = load_golden(name)
+    pn, bn, pc = oracle_state("finetune", c["classes"], False)
+    p = merged(pn, pc)
+    for v in p.values():
+        v.requires_grad_(True)
+    opt = S.Adam(p.values(), c["lr"], (0.9, 0.999), 1e-8, c["wd"])
+    ret = E.kather_sup_train(p, bn, opt, C.sup_batches_kather(name), c["hw"])
+    assert abs(ret[0] - g[f"{name}/ret"][0]) <= RT * g[f"{name}/ret"][0] and ret[1] == g[f"{name}/ret"][1]
+    check_snapshot(g, name, snapshot_dict(p, bn), RT)
+    val = E.kather_sup_validate(p, bn, C.val_batches_kather(name))
+    assert abs(val[0] - g[f"{name}/val"][0]) <= RT * g[f"{name}/val"][0] and val[1] == g[f"{name}/val"][1]
+
+
+def _load_into(p, b, sd):
+    """the oracle's load_state_dict: values of a (module.-stripped) reference state_dict into the functional dicts."""
+    with torch.no_grad():
+        for k, v in sd.items():
+            k = k[7:] if k.startswith("module.") else k
+            if k in p:
+                p[k].copy_(v)
+            else:
+                b[k] = v.clone()
+
+
+def test_checkpoint_continuation_ssl_cr():
+    """row f2: the oracle, started from the checkpoint the REFERENCE wrote after epoch 1 (rebuilt from the fixture), reproduces
+    the reference's epoch 2 -- parameters, BatchNorm buffers and Adam moments all come from the file."""
+    from _util import rebuild_ckpt
+    name = "ckpt_bpq_cr"
+    c = C.CASES[name]
+    g = load_golden(name)
+    sd0 = OM.init_state(C.PARAM_SEED, OM.net_param_specs(), random_running_stats=True)
+    cd0 = OM.init_state(C.PARAM_SEED + 1, OM.classifier_param_specs("finetune", 1))
+    ck, _ = rebuild_ckpt(name, {"model_student": (sd0, False), "model_teacher": (sd0, False),
+                                "classifier_student": (cd0, False), "classifier_teacher": (cd0, False)})
+    ps, bs, pt, bt = _student_teacher(1, c["modules"])
+    _load_into(ps, bs, ck["model_student"]); _load_into(ps, bs, ck["classifier_student"])
+    _load_into(pt, bt, ck["model_teacher"]); _load_into(pt, bt, ck["classifier_teacher"])
+    opt = S.Adam(ps.values(), c["lr"], (0.9, 0.999), 1e-8, c["wd"])
+    st = ck["optimizer"]["state"]
+    assert len(st) == len(opt.params)
+    for i in range(len(opt.params)):
+        opt.m[i].copy_(st[i]["exp_avg"]); opt.v[i].copy_(st[i]["exp_avg_sq"])
+    opt.t = int(st[0]["step"])
+    ret = E.bpq_cr_train(ps, bs, pt, bt, opt, C.labeled_batches(name, 1200), C.unlabeled_batches(name, 2200), c["lambda_u"])
+    for i in range(3):
+        assert abs(ret[i] - g[f"{name}/ret2"][i]) <= RT * abs(g[f"{name}/ret2"][i])
+    assert rel_err(ret[3], g[f"{name}/feats2"]) < RT
+    check_snapshot(g, name + "/e2", snapshot_dict(ps, bs), RT)
