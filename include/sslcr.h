@@ -236,6 +236,19 @@ int sslcr_destroy(sslcr_ctx* ctx);
  * reference (the reference's nn.DataParallel BN is per-replica, eval_BreastPathQ_SSL_CR.py:474-477). */
 int sslcr_comm_unique_id(void* id256);       /* two 128-byte RCCL ids: [0] BatchNorm sums (compute stream), [1] gradient buckets (side stream) */
 int sslcr_comm_init(sslcr_ctx* ctx, const void* id256, int rank, int world);
+/* what the communicator itself reports (ncclCommUserRank / ncclCommCount when RCCL is in use): rank, world, transport
+ * (0 none, 1 RCCL, 2 virtual ranks) -- bench.py prints it as ranks_seen. */
+int sslcr_comm_info(sslcr_ctx* ctx, int* rank, int* world, int* transport);
+/* "Virtual ranks" (test infrastructure for single-GPU boxes; RCCL refuses two ranks on one device): `world` contexts of ONE
+ * process on ONE device, one host thread and one stream each, exchange through a sslcr_vcomm instead of RCCL.  Every sharded
+ * code path of the engine -- synced BatchNorm sums forward and backward, global-count loss scaling, bucketed gradient sums on
+ * the side stream with their event joins -- runs exactly as with RCCL; only the transport differs (device-to-device copy +
+ * rank-ordered sum kernel behind a host rendezvous, asynchronous on the callers' streams).  The nn.DataParallel seam this
+ * replaces: eval_BreastPathQ_SSL_CR.py:474-477. */
+typedef struct sslcr_vcomm sslcr_vcomm;
+int sslcr_vcomm_create(sslcr_vcomm** out, int world);
+int sslcr_vcomm_destroy(sslcr_vcomm* v);
+int sslcr_comm_init_virtual(sslcr_ctx* ctx, sslcr_vcomm* v, int rank);
 /* on (default): synced BatchNorm as described above.  off: every rank normalises with its own shard's statistics -- the
  * semantics of the reference's nn.DataParallel replicas -- and only the gradient buckets are exchanged. */
 int sslcr_set_bn_sync(sslcr_ctx* ctx, int on);

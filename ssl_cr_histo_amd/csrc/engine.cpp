@@ -6,6 +6,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <vector>
 
 #include "kernels.hpp"
@@ -115,9 +118,32 @@ struct Profiler {               // optional HIP-event bracketing of the conv lau
   }
 };
 
+// "Virtual ranks": W engine contexts of ONE process on ONE device (one host thread and one stream each) exchange through this
+// object instead of RCCL -- every sharded code path of the engine (synced BatchNorm forward/backward sums, global-count loss
+// scaling, bucketed gradient sums on the side stream) then runs with world = W on a single-GPU box and can be compared with the
+// 1-rank step on the concatenated batch (tests/test_engine_gpu2.py).  RCCL refuses two ranks on one device, hence the stand-in;
+// it is deterministic (ranks summed in rank order) and asynchronous on the callers' streams like the real collective.
+constexpr int VW_MAX = 8;
+struct VChan {                      // one per collective stream (0: BatchNorm sums on the compute streams, 1: gradient buckets)
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  long gen = 0;
+  void* slot[2][VW_MAX] = {};       // [call parity][rank]: that rank's contribution, device memory owned by the rank
+  size_t cap[2][VW_MAX] = {};
+  hipEvent_t ev_in[2][VW_MAX] = {}, ev_out[2][VW_MAX] = {};
+  bool out_set[2][VW_MAX] = {};
+  long calls[VW_MAX] = {};
+};
+struct sslcr_vcomm {
+  int world = 1;
+  VChan ch[2];
+};
+
 struct sslcr_ctx {
   Profiler prof;
   int device = 0, dtype = 0;
+  sslcr_vcomm* vcomm = nullptr;   // set instead of comm / comm_g by sslcr_comm_init_virtual
   ncclComm_t comm = nullptr;      // BatchNorm-sum all-reduces, only ever used on the caller's (compute) stream
   ncclComm_t comm_g = nullptr;    // gradient buckets, only ever used on comm_stream (one communicator per stream, like
                                   // separate process groups: no cross-stream serialisation inside RCCL)
@@ -172,6 +198,71 @@ struct sslcr_net {
 };
 
 namespace {
+
+struct VSrc { const void* p[VW_MAX]; };
+template <typename T>
+__global__ void vsum_kernel(T* dst, VSrc src, int W, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    T s = static_cast<const T*>(src.p[0])[i];
+    for (int q = 1; q < W; ++q) s += static_cast<const T*>(src.p[q])[i];       // rank order: every rank gets the same bits
+    dst[i] = s;
+  }
+}
+
+inline bool sharded(const sslcr_ctx* c) { return c->comm != nullptr || c->vcomm != nullptr; }
+
+int vcomm_all_reduce(sslcr_ctx* c, int chan, void* buf, size_t count, bool f64, hipStream_t st) {
+  sslcr_vcomm* v = c->vcomm;
+  VChan& ch = v->ch[chan];
+  const int r = c->rank, W = v->world;
+  const size_t bytes = count * (f64 ? 8 : 4);
+  const int ph = (int)(ch.calls[r]++ & 1);
+  // the slot is reused every second call: its previous readers (the peers' sum kernels of two calls ago) recorded ev_out then
+  for (int q = 0; q < W; ++q)
+    if (q != r && ch.out_set[ph][q]) TRY(hipStreamWaitEvent(st, ch.ev_out[ph][q], 0));
+  if (ch.cap[ph][r] < bytes) {
+    if (ch.slot[ph][r]) TRY(hipFree(ch.slot[ph][r]));       // (synchronises the device)
+    ch.slot[ph][r] = nullptr; ch.cap[ph][r] = 0;
+    TRY(hipMalloc(&ch.slot[ph][r], (bytes + 255) & ~(size_t)255));
+    ch.cap[ph][r] = (bytes + 255) & ~(size_t)255;
+  }
+  if (!ch.ev_in[ph][r]) {
+    TRY(hipEventCreateWithFlags(&ch.ev_in[ph][r], hipEventDisableTiming));
+    TRY(hipEventCreateWithFlags(&ch.ev_out[ph][r], hipEventDisableTiming));
+  }
+  TRY(hipMemcpyAsync(ch.slot[ph][r], buf, bytes, hipMemcpyDeviceToDevice, st));
+  TRY(hipEventRecord(ch.ev_in[ph][r], st));
+  {                                                   // host rendezvous: every rank has published its slot and event
+    std::unique_lock<std::mutex> lk(ch.m);
+    const long g = ch.gen;
+    if (++ch.arrived == W) {
+      ch.arrived = 0; ++ch.gen;
+      ch.cv.notify_all();
+    } else if (!ch.cv.wait_for(lk, std::chrono::seconds(120), [&] { return ch.gen != g; })) {
+      --ch.arrived;
+      return fail("virtual all-reduce: rank %d waited 120 s for its peers (channel %d)", r, chan);
+    }
+  }
+  VSrc src;
+  for (int q = 0; q < W; ++q) {
+    src.p[q] = ch.slot[ph][q];
+    if (q != r) TRY(hipStreamWaitEvent(st, ch.ev_in[ph][q], 0));
+  }
+  const int blocks = (int)((count + 255) / 256 < 1024 ? (count + 255) / 256 : 1024);
+  if (f64) hipLaunchKernelGGL(vsum_kernel<double>, dim3(blocks), dim3(256), 0, st, (double*)buf, src, W, count);
+  else hipLaunchKernelGGL(vsum_kernel<float>, dim3(blocks), dim3(256), 0, st, (float*)buf, src, W, count);
+  TRY(hipGetLastError());
+  TRY(hipEventRecord(ch.ev_out[ph][r], st));
+  ch.out_set[ph][r] = true;
+  return 0;
+}
+
+// SUM all-reduce in place over the ranks of this job: channel 0 = BatchNorm sums (compute stream), 1 = gradient buckets (side stream)
+int all_reduce(sslcr_ctx* c, int chan, void* buf, size_t count, bool f64, hipStream_t st) {
+  if (c->vcomm) return vcomm_all_reduce(c, chan, buf, count, f64, st);
+  TRYN(ncclAllReduce(buf, buf, count, f64 ? ncclDouble : ncclFloat, ncclSum, chan == 0 ? c->comm : c->comm_g, st));
+  return 0;
+}
 
 // ---- launch wrappers: when profiling is on, bracket the kernel with HIP events on ITS stream and book the
 // algorithmic work (forward-conv FLOPs even for the strided dgrad gather, whose zero taps are not counted)
@@ -335,12 +426,12 @@ int finalize_bn(sslcr_net* n, const BnL& bn, const float* partials, int rows, do
   a.running_mean = n->bn_rm[bn.bidx]; a.running_var = n->bn_rv[bn.bidx]; a.num_batches_tracked = n->bn_nbt[bn.bidx];
   a.momentum = 0.1f; a.eps = 1e-5f; a.replay = replay;
   a.stage = c->bn_stage;
-  if (c->comm && c->bn_sync) {
+  if (sharded(c) && c->bn_sync) {
     // global-batch statistics: reduce rows -> [2][C] sums, all-reduce, finalize from the sums
     BnFinalizeArgs r = a;
     r.sums_out = c->bn_sums;
     TRY(launch_bn_finalize(r, st));
-    TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
+    TRYI(all_reduce(c, 0, c->bn_sums, 2 * (size_t)bn.C, true, st));
     a.sums_in = c->bn_sums;
     a.count = local_count * c->world;
   } else {
@@ -638,46 +729,58 @@ struct PoolSrc {            // gradient arriving through the stem max-pool (see 
   const void* dy; const uint8_t* argmax; int H, W, OH, OW; const void* y;
 };
 
-int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
-                void* dx, void* gout, size_t pixels, double count, hipStream_t st, const PoolSrc* pool = nullptr, int g_in_reduce = 0,
-                const float* sum_rows = nullptr, int n_sum_rows = 0) {
+// BatchNorm backward in three parts so that independent BatchNorms (a block's bn2 and its projection-shortcut BatchNorm) can
+// share ONE all-reduce of their sums: begin = the reduce pass into `sums` ([2][C] doubles), sync = the all-reduce, end = the apply pass
+int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
+                 void* dx, void* gout, size_t pixels, double count, hipStream_t st, double* sums, BnBwdArgs* out, const PoolSrc* pool = nullptr,
+                 int g_in_reduce = 0, const float* sum_rows = nullptr, int n_sum_rows = 0) {
   sslcr_ctx* c = n->ctx;
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.x = x; a.yact = yact; a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
-  a.sums = c->bn_sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
+  a.sums = sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
   a.g_in_reduce = (g_in_reduce && yact && gout) ? 1 : 0;
+  const bool synced = sharded(c) && c->bn_sync;
   if (n->rg[bn.pg] || n->rg[bn.pb]) {
     // dgamma/dbeta ride on the apply pass.  Synced BN: every rank holds the GLOBAL sums and the gradient all-reduce adds
     // `world` copies -> pre-divide (per-replica BN: the sums are this rank's share, the gradient all-reduce adds them up)
     a.dgamma = gptr(n, bn.pg); a.dbeta = gptr(n, bn.pb);
-    a.pg_scale = (c->comm && c->bn_sync) ? 1.0f / c->world : 1.0f;
+    a.pg_scale = synced ? 1.0f / c->world : 1.0f;
     if (!a.dgamma || !a.dbeta) { a.dgamma = nullptr; a.dbeta = nullptr; }
   }
   if (pool) { a.pool_dy = pool->dy; a.pool_argmax = pool->argmax; a.pH = pool->H; a.pW = pool->W; a.pOH = pool->OH; a.pOW = pool->OW; a.pool_y = pool->y; }
-  const bool synced = c->comm && c->bn_sync;
   a.count = synced ? count * c->world : count;
   if (sum_rows) {
     // the dgrad that produced dy already left partial rows of (sum g, sum g (x - mean)) (sslcr_conv_desc.mask_x): rows -> sums
     BnFinalizeArgs r;
     memset(&r, 0, sizeof(r));
-    r.partials = sum_rows; r.rows = n_sum_rows; r.C = bn.C; r.stage = c->bn_stage; r.sums_out = c->bn_sums;
+    r.partials = sum_rows; r.rows = n_sum_rows; r.C = bn.C; r.stage = c->bn_stage; r.sums_out = sums;
     TRY(launch_bn_finalize(r, st));
   } else {
-    TRY(hipMemsetAsync(c->bn_sums, 0, 2 * bn.C * sizeof(double), st));
+    TRY(hipMemsetAsync(sums, 0, 2 * bn.C * sizeof(double), st));
     TRY(launch_bn_bwd_reduce(c->dtype, a, st));
   }
-  if (synced) TRYN(ncclAllReduce(c->bn_sums, c->bn_sums, 2 * bn.C, ncclDouble, ncclSum, c->comm, st));
+  *out = a;
+  return 0;
+}
+
+int bn_bwd_sync(sslcr_ctx* c, double* sums, size_t count, hipStream_t st) {
+  if (sharded(c) && c->bn_sync) TRYI(all_reduce(c, 0, sums, count, true, st));
+  return 0;
+}
+
+int bn_bwd_end(sslcr_ctx* c, const BnBwdArgs& a, hipStream_t st) {
   if (c->prof.on) {
     ProfRec r;
     r.e0 = c->prof.get(); r.e1 = c->prof.get();
+    const bool pool = a.pool_dy != nullptr;
     if (pool) r.name = c->dtype == DT_BF16 ? "sslcr::bn_bwd_apply_pool_kernel<unsigned short>" : "sslcr::bn_bwd_apply_pool_kernel<float>";
     else r.name = c->dtype == DT_BF16 ? "sslcr::bn_bwd_apply_kernel<unsigned short>" : "sslcr::bn_bwd_apply_kernel<float>";
     r.flops = 0.0;
     // algorithmic bytes: read dy (or the 4x smaller pooled gradient + 1-byte argmax), x, (saved output for the ReLU mask); write dx (, g)
-    const double t = (double)pixels * bn.C * c->esz();
-    const double rd = (pool ? 0.25 * t + 0.25 * (double)pixels * bn.C : t) + t + ((yact && !a.g_in_reduce) ? t : 0.0);
-    r.bytes = rd + t + ((gout && !a.g_in_reduce) ? t : 0.0);
+    const double t = (double)a.pixels * a.C * c->esz();
+    const double rd = (pool ? 0.25 * t + 0.25 * (double)a.pixels * a.C : t) + t + ((a.yact && !a.g_in_reduce) ? t : 0.0);
+    r.bytes = rd + t + ((a.gout && !a.g_in_reduce) ? t : 0.0);
     (void)hipEventRecord(r.e0, st);
     hipError_t e = launch_bn_bwd_apply(c->dtype, a, st);
     (void)hipEventRecord(r.e1, st);
@@ -687,6 +790,16 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
     TRY(launch_bn_bwd_apply(c->dtype, a, st));
   }
   return 0;
+}
+
+int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
+                void* dx, void* gout, size_t pixels, double count, hipStream_t st, const PoolSrc* pool = nullptr, int g_in_reduce = 0,
+                const float* sum_rows = nullptr, int n_sum_rows = 0) {
+  sslcr_ctx* c = n->ctx;
+  BnBwdArgs a;
+  TRYI(bn_bwd_begin(n, bn, sv, dy, x, yact, relu_from_x, dx, gout, pixels, count, st, c->bn_sums, &a, pool, g_in_reduce, sum_rows, n_sum_rows));
+  TRYI(bn_bwd_sync(c, c->bn_sums, 2 * (size_t)bn.C, st));
+  return bn_bwd_end(c, a, st);
 }
 
 // seg_images > 0: the N images are N / seg_images segments (TripletNet branches) whose producer BatchNorms sit seg_stride floats apart
@@ -705,11 +818,11 @@ int wgrad_call(sslcr_net* n, const ConvL& L, const void* x, const void* dy, cons
 
 int launch_bucket_allreduce(sslcr_net* n, int bucket, size_t lo, size_t hi, hipStream_t st) {
   sslcr_ctx* c = n->ctx;
-  if (!c->comm_g || hi <= lo) return 0;
+  if (!sharded(c) || hi <= lo) return 0;
   TRY(hipEventRecord(c->ev_ready[bucket], st));
   TRY(hipStreamWaitEvent(c->comm_stream, c->ev_ready[bucket], 0));
   float* g = (float*)n->grads.p + lo;
-  TRYN(ncclAllReduce(g, g, hi - lo, ncclFloat, ncclSum, c->comm_g, c->comm_stream));
+  TRYI(all_reduce(c, 1, g, hi - lo, false, c->comm_stream));
   return 0;
 }
 
@@ -770,9 +883,19 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
            *dRawD = buf(kRawD, p, so);
       // bn2 (+ relu mask from the block output): its REDUCE pass leaves G = dOut * (y > 0) in scratch; the apply pass, the
       // projection shortcut's BatchNorm and the identity path all read G instead of (dOut, y) again
-      TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, nullptr, 1));
-      if (B.has_ds)
-        TRYI(bn_backward(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st));
+      // ... and with a projection shortcut the two reduce passes run back to back, so that sharded runs exchange both
+      // BatchNorms' sums ([2][C] each, adjacent in bn_sums) in ONE all-reduce before the two apply passes
+      if (B.has_ds) {
+        BnBwdArgs a2, ad;
+        double* sums_d = c->bn_sums + 2 * B.b2.C;
+        TRYI(bn_bwd_begin(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, c->bn_sums, &a2, nullptr, 1));
+        TRYI(bn_bwd_begin(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st, sums_d, &ad));
+        TRYI(bn_bwd_sync(c, c->bn_sums, 4 * (size_t)B.b2.C, st));
+        TRYI(bn_bwd_end(c, a2, st));
+        TRYI(bn_bwd_end(c, ad, st));
+      } else {
+        TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, nullptr, 1));
+      }
       if (!c2_batched) TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
       float* b1_rows = nullptr;
       int b1_nrows = 0;
@@ -907,7 +1030,7 @@ int net_backward(sslcr_net* n, const float* dlogits, hipStream_t st) {
   if (bb) {
     TRYI(backbone_backward(n, npass, st));
   }
-  if (c->comm_g) {
+  if (sharded(c)) {
     TRY(hipEventRecord(c->ev_done, c->comm_stream));
     TRY(hipStreamWaitEvent(st, c->ev_done, 0));
   }
@@ -923,10 +1046,10 @@ int sslcr_create(sslcr_ctx** out, int device, int dtype) {
   TRY(hipSetDevice(device));
   sslcr_ctx* c = new sslcr_ctx();
   c->device = device; c->dtype = dtype;
-  if (c->small.ensure(32 * 2 * 512 * sizeof(double) + 2 * 512 * sizeof(double) + 2 * 512 * sizeof(float)) != 0) { delete c; return -1; }
+  if (c->small.ensure(32 * 2 * 512 * sizeof(double) + 2 * 2 * 512 * sizeof(double) + 2 * 512 * sizeof(float)) != 0) { delete c; return -1; }
   c->bn_stage = (double*)c->small.p;
-  c->bn_sums = c->bn_stage + 32 * 2 * 512;
-  c->ones = (float*)(c->bn_sums + 2 * 512);
+  c->bn_sums = c->bn_stage + 32 * 2 * 512;        // two [2][C] slots (bn2 + projection BatchNorm of a block share an all-reduce)
+  c->ones = (float*)(c->bn_sums + 2 * 2 * 512);
   c->zeros = c->ones + 512;
   TRY(launch_fill(c->ones, 512, 1.f, nullptr));
   TRY(launch_fill(c->zeros, 512, 0.f, nullptr));
@@ -943,8 +1066,8 @@ int sslcr_destroy(sslcr_ctx* c) {
     (void)hipEventDestroy(c->ev_aux_begin);
     (void)hipEventDestroy(c->ev_aux_end);
   }
-  if (c->comm) {
-    ncclCommDestroy(c->comm);
+  if (c->comm || c->vcomm) {
+    if (c->comm) ncclCommDestroy(c->comm);
     if (c->comm_g) ncclCommDestroy(c->comm_g);
     (void)hipStreamDestroy(c->comm_stream);
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev_ready[i]);
@@ -1040,6 +1163,51 @@ int sslcr_comm_init(sslcr_ctx* c, const void* id256, int rank, int world) {
   for (int i = 0; i < 8; ++i) TRY(hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming));
   TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   c->rank = rank; c->world = world;
+  return 0;
+}
+
+int sslcr_comm_info(sslcr_ctx* c, int* rank, int* world, int* transport) {
+  if (!c) return fail("sslcr_comm_info: null");
+  int r = c->rank, w = c->world;
+  if (c->comm) {                 // what RCCL itself says, not what the caller passed
+    TRYN(ncclCommUserRank(c->comm, &r));
+    TRYN(ncclCommCount(c->comm, &w));
+  }
+  if (rank) *rank = r;
+  if (world) *world = w;
+  if (transport) *transport = c->comm ? 1 : c->vcomm ? 2 : 0;
+  return 0;
+}
+
+int sslcr_vcomm_create(sslcr_vcomm** out, int world) {
+  if (!out || world < 1 || world > VW_MAX) return fail("sslcr_vcomm_create: world must be 1..%d", VW_MAX);
+  sslcr_vcomm* v = new sslcr_vcomm();
+  v->world = world;
+  *out = v;
+  return 0;
+}
+
+int sslcr_vcomm_destroy(sslcr_vcomm* v) {
+  if (!v) return 0;
+  (void)hipDeviceSynchronize();
+  for (auto& ch : v->ch)
+    for (int ph = 0; ph < 2; ++ph)
+      for (int q = 0; q < VW_MAX; ++q) {
+        if (ch.slot[ph][q]) (void)hipFree(ch.slot[ph][q]);
+        if (ch.ev_in[ph][q]) { (void)hipEventDestroy(ch.ev_in[ph][q]); (void)hipEventDestroy(ch.ev_out[ph][q]); }
+      }
+  delete v;
+  return 0;
+}
+
+int sslcr_comm_init_virtual(sslcr_ctx* c, sslcr_vcomm* v, int rank) {
+  if (!c || !v || rank < 0 || rank >= v->world) return fail("sslcr_comm_init_virtual: invalid argument");
+  if (c->comm || c->vcomm) return fail("sslcr_comm_init_virtual: this context already has a communicator");
+  TRY(hipSetDevice(c->device));
+  TRY(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; ++i) TRY(hipEventCreateWithFlags(&c->ev_ready[i], hipEventDisableTiming));
+  TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+  c->vcomm = v; c->rank = rank; c->world = v->world;
   return 0;
 }
 

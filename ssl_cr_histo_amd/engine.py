@@ -35,6 +35,10 @@ _ENGINE_SIGS = {
     "sslcr_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "sslcr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "sslcr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "sslcr_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sslcr_vcomm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "sslcr_vcomm_destroy": (C.c_int, [C.c_void_p]),
+    "sslcr_comm_init_virtual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "sslcr_set_bn_sync": (C.c_int, [C.c_void_p, C.c_int]),
     "sslcr_set_aux_stream": (C.c_int, [C.c_void_p, C.c_int]),
     "sslcr_net_create": (C.c_int, [C.c_void_p, C.POINTER(SslcrNetDesc), C.POINTER(C.c_void_p)]),
@@ -258,6 +262,19 @@ class Engine:
         L.check(L.lib().sslcr_comm_init(self.handle, idbuf, rank, world))
         self.rank, self.world = rank, world
 
+    def init_comm_virtual(self, vcomm, rank, world):
+        """join a VirtualComm (world contexts of one process on one device, see include/sslcr.h): test infrastructure that runs
+        the engine's sharded code paths on a single-GPU box."""
+        L.check(L.lib().sslcr_comm_init_virtual(self.handle, vcomm.handle, rank))
+        self.rank, self.world = rank, world
+        self._vcomm = vcomm                                        # keep it alive as long as this engine
+
+    def comm_info(self):
+        """(rank, world, transport) as the communicator itself reports them; transport: 'none' | 'rccl' | 'virtual'."""
+        r, w, t = C.c_int(), C.c_int(), C.c_int()
+        L.check(L.lib().sslcr_comm_info(self.handle, C.byref(r), C.byref(w), C.byref(t)))
+        return r.value, w.value, ("none", "rccl", "virtual")[t.value]
+
     def set_bn_sync(self, on):
         """True (default): train-mode BatchNorm uses global-batch statistics across ranks; False: per-replica statistics
         like the reference's nn.DataParallel (eval_BreastPathQ_SSL_CR.py:474-477)."""
@@ -380,6 +397,24 @@ class Engine:
         if train:
             net._note_buffers_changed()
         return dict(losses=losses, feats=feats, logits=logits)
+
+
+class VirtualComm:
+    """shared exchange object of `world` virtual ranks (see include/sslcr.h: sslcr_vcomm)."""
+
+    def __init__(self, world):
+        lib = L.lib()
+        for name in ("sslcr_vcomm_create", "sslcr_vcomm_destroy", "sslcr_comm_init_virtual"):
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = _ENGINE_SIGS[name]
+        h = C.c_void_p()
+        L.check(lib.sslcr_vcomm_create(C.byref(h), world))
+        self.handle, self.world = h, world
+
+    def close(self):
+        if self.handle:
+            L.lib().sslcr_vcomm_destroy(self.handle)
+            self.handle = None
 
 
 _engines = {}

@@ -274,12 +274,14 @@ def test_checkpoint_pretrain_resume_continues_like_the_reference(dtype, tmp_path
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["traj_bpq_cr", "traj_cam_cr"])
 def test_trajectory_vs_reference(name, dtype):
-    """12 consecutive iterations of the reference's own train() (one call per iteration, one optimizer object, 256x256, full
+    """24 consecutive iterations of the reference's own train() (one call per iteration, one optimizer object, 256x256, full
     fine-tune; Adam / MSE for BreastPathQ, SGD-Nesterov / CE + pseudo-label CE for Camelyon), per-iteration returned losses,
     validate() every 4 iterations, final snapshot.  fp32 mode is held to the north-star 1e-3 on EVERY iteration's losses.
-    bf16 mode (the mode the throughput is quoted in) is measured: its per-iteration deviation is printed and must stay inside
-    6e-2 WITHOUT growing -- the mean deviation of the last four iterations may not exceed twice that of the first four (+0.5 %):
-    bf16 storage noise perturbs each step, it does not accumulate into a different training run."""
+    bf16 mode (the mode the throughput is quoted in) is measured, printed and bounded: every iteration's losses within 3e-2 of the
+    reference's, and the deviation must not keep growing -- the mean of the last eight iterations may not exceed 1.3 x the mean of
+    iterations 9-16 (+0.2 %).  Measured: SGD-Nesterov / Camelyon stays at 0.3-2.5e-3 throughout; Adam / BreastPathQ (where every
+    noisy gradient component becomes a full lr-sized step) climbs from 1e-3 to 1.4e-2 over the first twelve iterations while the
+    loss itself falls by 30 %, then stays at 1.4-1.6e-2: a bounded offset, not a diverging run."""
     from ssl_cr_histo_amd import steps
     _engine(dtype)
     c = C.CASES[name]
@@ -311,17 +313,126 @@ def test_trajectory_vs_reference(name, dtype):
                 v = (steps.bpq_cr_validate(ns(), ms, cs, C.val_batches_reg(name), 1),)
             vdev.append(abs(v[0] - wvals[len(vdev)][0]) / abs(wvals[len(vdev)][0]))
     print(f"[{dtype}] {name}: per-iteration max relative loss deviation from the reference:\n   " + " ".join(f"{d:.2e}" for d in dev) +
-          "\n   validate() after 4/8/12 iterations: " + " ".join(f"{d:.2e}" for d in vdev))
+          "\n   validate() after every 4th iteration: " + " ".join(f"{d:.2e}" for d in vdev))
     if dtype == "fp32":
         assert max(dev) <= 1e-3, dev
         assert max(vdev) <= 5e-3, vdev
-        # 2e-2 on the state: a conv weight in front of a BatchNorm has directions the loss does not depend on (scale, per-channel
+        # 5e-2 on the state: a conv weight in front of a BatchNorm has directions the loss does not depend on (scale, per-channel
         # offset); their true gradient is zero, what two fp32 implementations compute there is round-off of opposite sign, and
         # Adam turns any nonzero gradient into a step of size lr -- so pre-BatchNorm means (running_mean) drift apart by ~lr per
-        # iteration while losses, features and validate() stay within 1e-3 (measured: 1e-2 on layer4.1.bn2.running_mean)
-        check_snapshot(g, name, state_of(ms, cs), 2e-2)
+        # iteration while the training losses stay within 6e-4 and validate() within 5e-3 (measured on layer4.1.bn2.running_mean:
+        # 1e-2 after 12 iterations, 2.2e-2 after 24)
+        check_snapshot(g, name, state_of(ms, cs), 5e-2)
     else:
-        assert max(dev) <= 6e-2, dev
-        head, tail = float(np.mean(dev[:4])), float(np.mean(dev[-4:]))
-        assert tail <= 2.0 * head + 5e-3, (head, tail, dev)
-        assert max(vdev) <= 0.15, vdev
+        assert max(dev) <= 3e-2, dev
+        mid, tail = float(np.mean(dev[8:16])), float(np.mean(dev[-8:]))
+        assert tail <= 1.3 * mid + 2e-3, (mid, tail, dev)
+        assert max(vdev) <= 5e-2, vdev
+
+
+# ------------------------------------------------------------------------------------------------ e: virtual ranks on one GPU
+def _run_ranks(world, fn):
+    """fn(rank) on `world` host threads, one torch stream each; re-raises the first failure."""
+    import threading
+    out, err = [None] * world, [None] * world
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(world)]
+
+    def body(r):
+        try:
+            torch.cuda.set_device(torch.device(DEV))
+            with torch.cuda.stream(streams[r]):
+                out[r] = fn(r)
+                streams[r].synchronize()
+        except BaseException as e:          # noqa: BLE001 -- reported below
+            err[r] = e
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("workload", ["ssl_cr_ce", "ssl_cr_mse", "rsp"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_virtual_ranks_equal_the_single_device_step(world, workload, dtype):
+    """The engine's SHARDED code path against its own 1-rank step on the concatenated batch: `world` contexts on this one GPU,
+    each with 1/world of the batch, exchanging through the virtual communicator (include/sslcr.h: sslcr_vcomm -- same call sites
+    as RCCL: per-layer (sum, sum^2) all-reduce + global count in every train-mode BatchNorm forward, (sum g, sum g(x - mean))
+    in backward, loss scaled by the GLOBAL batch, five gradient buckets summed on the side stream and joined before the
+    optimizer).  Every rank must end with the single-device gradient (all 66/68 parameters), losses that add up to the
+    single-device loss, the single-device BatchNorm running statistics and, after the optimizer step, the same parameters.
+    fp32: 2e-5 relative L2 per gradient (summation order only).  bf16 mode: a last-bit difference in a BatchNorm scale (fp64 sums
+    added in another order) re-rounds some bf16 activations, and on this tiny random-weight problem bf16 rounding noise alone is
+    worth tens of percent on the backbone gradients (oracle/bf16_emul.py; tools/bf16_sources.py; measured here: a flat 16 % from
+    conv1 to fc.0 with losses equal to 5e-4) -- so bf16 is only held to 0.6 on the gradients, 1e-2 on the losses and 0.1 on the post-step state (lr 1e-2 SGD of those gradients); the arithmetic is pinned by the fp32 rows."""
+    from ssl_cr_histo_amd import engine as E
+    hw = 64
+    rsp = workload == "rsp"
+    kind = "mse" if workload == "ssl_cr_mse" else "ce"
+    classes = 6 if rsp else (1 if kind == "mse" else 2)
+    nx, nu = 2 * world, 3 * world
+
+    def nets():
+        if rsp:
+            return build("triplet", "mlp", 6, False)
+        return build("finetune", "finetune", classes, True)
+    if rsp:
+        xs = [C.u8(8300 + j, (nx, 3, hw, hw)) for j in range(3)]
+        y = C.ints(8310, (nx,), 6)
+    else:
+        x, u_w, u_s = C.u8(8320, (nx, 3, hw, hw)), C.u8(8321, (nu, 3, hw, hw)), C.u8(8322, (nu, 3, hw, hw))
+        y = C.f32(8323, (nx,)) if kind == "mse" else C.ints(8323, (nx,), 2)
+
+    def one_step(eng, r, w):
+        lo_x, hi_x = r * nx // w, (r + 1) * nx // w
+        lo_u, hi_u = r * nu // w, (r + 1) * nu // w
+        ms, cs = nets()
+        ms.train(); cs.train()
+        st = eng.bind(ms, cs)
+        opt = torch.optim.SGD(list(ms.parameters()) + list(cs.parameters()), lr=1e-2, momentum=0.9, weight_decay=1e-4, nesterov=True)
+        if rsp:
+            res = eng.step_supervised(st, "ce", [v[lo_x:hi_x] for v in xs], y[lo_x:hi_x], train=True, n_global=nx)
+        else:
+            mt, ct = nets()
+            freeze(mt, 64)
+            mt.eval(); ct.eval()
+            te = eng.bind(mt, ct)
+            res = eng.step_ssl_cr(te, st, kind, x[lo_x:hi_x], y[lo_x:hi_x], u_w[lo_u:hi_u], u_s[lo_u:hi_u], 0.7, nx_global=nx, nu_global=nu)
+        grads = [st.grad(i).cpu().double() for i in range(len(st.params))]
+        st.optimizer_step(opt)
+        torch.cuda.current_stream().synchronize()
+        return dict(losses=res["losses"].cpu().double(), grads=grads, state=state_of(ms, cs))
+
+    single = one_step(E.Engine(DEV, dtype), 0, 1)
+    vc = E.VirtualComm(world)
+    engines = [E.Engine(DEV, dtype) for _ in range(world)]
+    for r, e in enumerate(engines):
+        e.init_comm_virtual(vc, r, world)
+        assert e.comm_info() == (r, world, "virtual")
+    ranks = _run_ranks(world, lambda r: one_step(engines[r], r, world))
+    tg, tl, tsn = (2e-5, 1e-5, 1e-5) if dtype == "fp32" else (0.6, 1e-2, 0.1)
+    total = sum(o["losses"] for o in ranks)
+    assert torch.allclose(total[:3], single["losses"][:3], rtol=tl, atol=1e-7), (total, single["losses"])
+    assert abs(float(total[3] - single["losses"][3])) <= (0 if dtype == "fp32" else 2)           # correct-prediction counts add up
+    worst = 0.0
+    prof = [float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(ranks[0]["grads"], single["grads"])]
+    print(f"[{dtype}] {workload} world {world}: losses {total.tolist()} vs {single['losses'].tolist()}\n   rank-0 gradient deviation by parameter: " +
+          " ".join(f"{e:.1e}" for e in prof))
+    for r, o in enumerate(ranks):
+        for i, (a, b) in enumerate(zip(o["grads"], single["grads"])):
+            e = float((a - b).norm() / (b.norm() + 1e-30))
+            worst = max(worst, e)
+            assert e <= (tg if dtype == "fp32" else 0.6), (r, i, e)
+        for k, v in single["state"].items():
+            if "num_batches" in k:
+                assert int(o["state"][k]) == int(v), k
+            else:
+                assert float((o["state"][k].double() - v.double()).norm() / (v.double().norm() + 1e-30)) <= tsn, (r, k)
+    print(f"[{dtype}] {workload} world {world}: worst per-parameter gradient deviation from the single-device step {worst:.2e}")
+    for e in engines:
+        del e
