@@ -2,18 +2,23 @@
 """Headline benchmark: images/s of the ResNet18 SSL_CR (teacher-student consistency) training step on synthetic
 256x256 uint8 patches, bf16 engine mode, one process per GPU.
 
-  python bench.py [--gpus N --steps K --warmup W]                      (N=1 by default)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N>1, RCCL over xGMI)
+  python bench.py [--gpus N --steps K --warmup W]      N=1 by default; N>1 re-executes itself through
+                                                       `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (what the driver runs for N>1)
 
 A step = one iteration of eval_BreastPathQ_SSL_CR.train() at the per-GPU shapes of BASELINE config 4
 (`--batch_size 512 --mu 7` over 8 GPUs -> b=64/GPU: 192 labeled + 448 strong-unlabeled student images, 448 weak-unlabeled
 teacher images = 1088 distinct patches), full fine-tune (--modules_student 0), MSE+MSE loss, Adam: teacher eval forward,
 student train-mode forward, losses, full backward, gradient all-reduce (N>1), fused Adam update.  Weak scaling: the
-per-GPU batch is fixed.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+per-GPU batch is fixed.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0; at N=1 the line
+also carries the other BASELINE.json configurations measured in the same process (`also`: forward-only = config 2, RSP = config 3,
+the reference-default frozen backbone, and the fp32 exact-parity mode) and the CPU baseline of BASELINE.md section 3.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 F_FWD = 2 * 2368733184            # backbone forward FLOPs per 256x256 image
 F_BWD_FULL = 2 * F_FWD - 0.308e9  # + dgrad + wgrad, no dgrad for conv1
+PMC_FILE = os.path.join("profiles", "r02_pmc_step.json")     # tools/pmc_step.sh: counters of THIS command, per kernel
 
 
 def parse():
@@ -45,6 +51,8 @@ def parse():
                          "default because concurrent launches make the per-kernel durations of the roofline leg meaningless")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the other configurations (forward-only, RSP, frozen, fp32 parity)")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -53,7 +61,7 @@ def synth_u8(shape, seed, device):
     return torch.randint(0, 256, shape, dtype=torch.uint8, generator=g).to(device)
 
 
-def build_nets(args, device, classes=1, triplet=False):
+def build_nets(device, classes=1, triplet=False):
     from ssl_cr_histo_amd import net
     torch.manual_seed(42)                                   # the reference's default --seed
     if triplet:
@@ -63,57 +71,212 @@ def build_nets(args, device, classes=1, triplet=False):
     return model.to(device), cls.to(device)
 
 
-def cpu_baseline(args):
-    """oracle (CPU restatement of the reference step, torch CPU fp32) timed on this box's host cores, bounded sample."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+CPU_BASELINE_WALL_S = 80.0        # hard bound on the whole leg (the child process is killed at the deadline)
+
+
+def cpu_baseline_child(args):
+    """runs in a child process (`bench.py --cpu-baseline-child`): one JSON line per finished leg, most important legs first."""
     from collections import OrderedDict
     from oracle import model as OM, steps as S
-    # torch-CPU convolutions on a 17-image batch stop scaling (and collapse) far below a 256-thread host: use 32 threads
-    threads = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
-    hw, b, mu = args.image_size, 1, args.mu
+    hw, b, mu = args.image_size, 2, args.mu
     nx, nu = 3 * b, mu * b
+    patches = nx + 2 * nu
     sd = OM.init_state(42, OM.net_param_specs())
     csd = OM.init_state(43, OM.classifier_param_specs("finetune", 1))
-    def mk():
-        p, bufs = OM.split_state(OrderedDict((k, v.clone()) for k, v in sd.items()))
-        pc, _ = OM.split_state(OrderedDict((k, v.clone()) for k, v in csd.items()))
-        p.update(pc)
-        return p, bufs
-    ps, bs = mk()
-    pt, bt = mk()
-    for i, v in enumerate(ps.values()):
-        v.requires_grad_(i >= args.modules_student)
-    opt = S.Adam(ps.values(), 1e-4, (0.9, 0.999), 1e-8, 1e-4)
     g = torch.Generator().manual_seed(1234)
     x = torch.randint(0, 256, (nx, 3, hw, hw), generator=g).float()
     u_w = torch.randint(0, 256, (nu, 3, hw, hw), generator=g).float()
     u_s = torch.randint(0, 256, (nu, 3, hw, hw), generator=g).float()
     y = torch.rand(nx, generator=g)
-    times = []
-    budget_t0 = time.time()
-    for it in range(3):
-        t0 = time.time()
-        S.ssl_cr_step("mse", ps, bs, pt, bt, opt, x, y, u_w, u_s, 1.0, faithful=True)
-        times.append(time.time() - t0)
-        if it >= 1 and time.time() - budget_t0 > 30.0:       # bounded: ~10-30 s of CPU work
-            break
-    t = min(times[1:]) if len(times) > 1 else times[0]
-    patches = nx + 2 * nu
-    return {"value": round(patches / t, 2), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"oracle ssl_cr_step (faithful: 3 backbone passes per image like models/net.py:88-90), b={b} mu={mu} "
-                      f"-> {nx} labeled + {nu}+{nu} unlabeled {hw}x{hw} patches, modules_student={args.modules_student}, "
-                      f"fp32 torch-CPU, {threads} threads of {os.cpu_count()} host cores, best of {max(1, len(times) - 1)} timed "
-                      f"step(s) after 1 warm-up ({t:.2f} s/step)"}
+
+    def leg(threads, faithful, budget_s, warm=1):
+        print(json.dumps({"started": True, "threads": threads, "variant": "faithful" if faithful else "algorithmic"}), flush=True)
+        torch.set_num_threads(threads)
+
+        def mk():
+            p, bufs = OM.split_state(OrderedDict((k, v.clone()) for k, v in sd.items()))
+            pc, _ = OM.split_state(OrderedDict((k, v.clone()) for k, v in csd.items()))
+            p.update(pc)
+            return p, bufs
+        ps, bs = mk()
+        pt, bt = mk()
+        for i, v in enumerate(ps.values()):
+            v.requires_grad_(i >= args.modules_student)
+        opt = S.Adam(ps.values(), 1e-4, (0.9, 0.999), 1e-8, 1e-4)
+        times, t_begin = [], time.time()
+        for it in range(warm + 5):                                     # median of at most 5 timed steps
+            t0 = time.time()
+            S.ssl_cr_step("mse", ps, bs, pt, bt, opt, x, y, u_w, u_s, 1.0, faithful=faithful)
+            if it >= warm:
+                times.append(time.time() - t0)
+            if times and time.time() - t_begin > budget_s:            # bounded: stop adding steps once the share is used
+                break
+        times.sort()
+        med = times[len(times) // 2]
+        print(json.dumps({"threads": threads, "variant": "faithful" if faithful else "algorithmic",
+                          "images_per_s": round(patches / med, 2), "s_per_step": round(med, 3), "timed_steps": len(times),
+                          "warmup_steps": warm, "patches_per_step": patches}), flush=True)
+    ncpu = os.cpu_count() or 1
+    t32 = min(32, ncpu)
+    leg(t32, True, 14.0)
+    leg(t32, False, 8.0)
+    leg(1, False, 0.0, warm=0)              # one single-thread step, no warm-up: order of magnitude per core
+    if ncpu != t32:                         # all logical cores: torch-CPU convolutions on a 34-image batch collapse far below a
+        leg(ncpu, False, 8.0)               # 256-thread host (measured: not one step in 3 min) -- whatever finishes inside the wall
+        leg(ncpu, True, 14.0)
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement of the reference step, torch-CPU fp32, proved equal to the reference's train() on the
+    committed goldens) timed on this box's host cores: config C4 at b=2, mu=7 (student 20 / teacher 14 images, 34 distinct
+    patches per step), full fine-tune, Adam -- FAITHFUL (three backbone passes per image, models/net.py:88-90: what the
+    reference executes) and ALGORITHMIC (one pass), at 32 threads (median of up to 5 timed steps after one warm-up), one single-thread
+    step of the algorithmic variant, then the same two variants at os.cpu_count() threads as far as the wall bound allows.  Bounded: every leg stops adding steps once its
+    share is used, and the whole thing runs in a child process that is killed at CPU_BASELINE_WALL_S (legs finished by then
+    count).  `value` = the best faithful leg (the reference-equivalent baseline of record)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--image_size", str(args.image_size), "--mu", str(args.mu),
+           "--modules_student", str(args.modules_student)]
+    env = dict(os.environ)
+    env["HIP_VISIBLE_DEVICES"] = ""                                   # the child never touches the GPU
+    t0 = time.time()
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env)
+    timed_out = False
+    try:
+        stdout, _ = proc.communicate(timeout=CPU_BASELINE_WALL_S)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        proc.kill()
+        stdout, _ = proc.communicate()
+    lines = [json.loads(l) for l in stdout.splitlines() if l.startswith("{")]
+    legs = [l for l in lines if not l.get("started")]
+    if timed_out and lines and lines[-1].get("started"):              # the leg that was running when the wall bound hit
+        legs.append({"threads": lines[-1]["threads"], "variant": lines[-1]["variant"], "finished": False,
+                     "note": f"killed at the {CPU_BASELINE_WALL_S:.0f} s wall bound of the whole CPU leg"})
+    ncpu = os.cpu_count() or 1
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    faithful = [l for l in legs if l["variant"] == "faithful" and l.get("finished", True)]
+    if not faithful:
+        return {"value": None, "unit": "images/s", "cores": 0, "kind": "port", "sample": "no leg finished inside the wall bound",
+                "host": {"cpu": cpu_model, "logical_cores": ncpu}, "legs": legs, "timed_out": timed_out}
+    best = max(faithful, key=lambda l: l["images_per_s"])
+    b, mu, hw = 2, args.mu, args.image_size
+    return {"value": best["images_per_s"], "unit": "images/s", "cores": best["threads"], "kind": "port",
+            "sample": f"oracle ssl_cr_step (CPU restatement of eval_BreastPathQ_SSL_CR.train, torch-CPU fp32), config C4 at b={b} mu={mu}: "
+                      f"{3 * b} labeled + {mu * b}+{mu * b} unlabeled {hw}x{hw} patches = {best['patches_per_step']} distinct patches/step, "
+                      f"modules_student={args.modules_student}, Adam; value = FAITHFUL variant (3 backbone passes per image like "
+                      f"models/net.py:88-90) at {best['threads']} threads, median of {best['timed_steps']} timed step(s) after 1 warm-up "
+                      f"({best['s_per_step']} s/step); all legs in `legs`",
+            "host": {"cpu": cpu_model, "logical_cores": ncpu}, "legs": legs, "wall_s": round(time.time() - t0, 1),
+            "timed_out": timed_out}
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def make_workload(name, eng, args, device, rank, world, modules_student=None):
+    """-> (step(), distinct patches per step, algorithmic FLOPs per step, config dict)"""
+    hw, b, mu = args.image_size, args.batch_size, args.mu
+    ms_freeze = args.modules_student if modules_student is None else modules_student
+    lr, wd = 1e-4, 1e-4
+    if name == "ssl_cr":
+        nx, nu = 3 * b, mu * b
+        mt, ct = build_nets(device)
+        ms, cs = build_nets(device)
+        for m in (mt, ct):
+            m.eval()
+        for m in (ms, cs):
+            m.train()
+        for p in list(mt.parameters()) + list(ct.parameters()):
+            p.requires_grad = False
+        for i, (_, p) in enumerate(ms.named_parameters()):
+            p.requires_grad = i >= ms_freeze
+        te, st = eng.bind(mt, ct), eng.bind(ms, cs)
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())), lr=lr,
+                               betas=(0.9, 0.999), weight_decay=wd)
+        x = synth_u8((nx, 3, hw, hw), 1234 + rank, device)
+        u_w = synth_u8((nu, 3, hw, hw), 2234 + rank, device)
+        u_s = synth_u8((nu, 3, hw, hw), 3234 + rank, device)
+        y = torch.rand(nx, generator=torch.Generator().manual_seed(4234 + rank)).to(device)
+
+        def step():
+            r = eng.step_ssl_cr(te, st, "mse", x, y, u_w, u_s, 1.0)
+            st.optimizer_step(opt)
+            return r
+        flops = nu * F_FWD + (nx + nu) * (F_FWD + (F_BWD_FULL if ms_freeze == 0 else 0))
+        cfg = {"workload": f"eval_BreastPathQ_SSL_CR.train step, per-GPU --batch_size {b} --mu {mu}: student {nx}+{nu}, teacher {nu} "
+                           f"({nx + 2 * nu} distinct {hw}x{hw} uint8 patches/step/GPU), modules_student={ms_freeze}, Adam",
+               "global_batch_patches": (nx + 2 * nu) * world, "parallelism": f"dp{world}", "backward": ms_freeze < 60,
+               "bn_sync": bool(args.bn_sync) if world > 1 else None, "aux_stream": bool(args.aux_stream)}
+        return step, nx + 2 * nu, flops, cfg, (mt, ct, ms, cs, opt)
+    if name == "fwd":
+        n = 4 * b
+        ms, cs = build_nets(device)
+        ms.eval()
+        st = eng.bind(ms, cs)
+        x = synth_u8((n, 3, hw, hw), 1234 + rank, device)
+
+        def step():
+            return st.forward((x,), train=False)
+        cfg = {"workload": f"ResNet18 TripletNet_Finetune forward-only (eval BN folded), N={n} {hw}x{hw}", "parallelism": f"dp{world}"}
+        return step, n, n * F_FWD, cfg, (ms, cs)
+    B = 2 * b
+    ms, cs = build_nets(device, triplet=True)
+    ms.train()
+    st = eng.bind(ms, cs)
+    opt = torch.optim.SGD(list(ms.parameters()) + list(cs.parameters()), lr=0.01, momentum=0.9, weight_decay=wd, nesterov=True)
+    xs = [synth_u8((B, 3, hw, hw), 1234 + 10 * i + rank, device) for i in range(3)]
+    y = torch.randint(0, 6, (B,), generator=torch.Generator().manual_seed(5234 + rank)).to(device)
+
+    def step():
+        r = eng.step_supervised(st, "ce", xs, y, train=True)
+        st.optimizer_step(opt)
+        return r
+    cfg = {"workload": f"pretrain_BreastPathQ.train step (RSP), B={B} triplets {hw}x{hw}, SGD-Nesterov", "parallelism": f"dp{world}"}
+    return step, 3 * B, 3 * B * (F_FWD + F_BWD_FULL), cfg, (ms, cs, opt)
+
+
+def timed(step, warmup, steps, barrier):
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-execute through torch.distributed.run, one rank per GPU."""
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
     args = parse()
+    if args.cpu_baseline_child:
+        return cpu_baseline_child(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
@@ -127,87 +290,20 @@ def main():
     eng.set_bn_sync(bool(args.bn_sync))
     eng.set_aux_stream(bool(args.aux_stream))
 
-    hw, b, mu = args.image_size, args.batch_size, args.mu
-    lr, wd = 1e-4, 1e-4
-    if args.workload == "ssl_cr":
-        nx, nu = 3 * b, mu * b
-        mt, ct = build_nets(args, device)
-        ms, cs = build_nets(args, device)
-        for m in (mt, ct):
-            m.eval()
-        for m in (ms, cs):
-            m.train()
-        for p in list(mt.parameters()) + list(ct.parameters()):
-            p.requires_grad = False
-        for i, (_, p) in enumerate(ms.named_parameters()):
-            p.requires_grad = i >= args.modules_student
-        te, st = eng.bind(mt, ct), eng.bind(ms, cs)
-        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())), lr=lr,
-                               betas=(0.9, 0.999), weight_decay=wd)
-        x = synth_u8((nx, 3, hw, hw), 1234 + rank, device)
-        u_w = synth_u8((nu, 3, hw, hw), 2234 + rank, device)
-        u_s = synth_u8((nu, 3, hw, hw), 3234 + rank, device)
-        y = torch.rand(nx, generator=torch.Generator().manual_seed(4234 + rank)).to(device)
-        patches = nx + 2 * nu
-
-        def step():
-            r = eng.step_ssl_cr(te, st, "mse", x, y, u_w, u_s, 1.0)
-            st.optimizer_step(opt)
-            return r
-        bwd = args.modules_student < 60
-        flops_step = nu * F_FWD + (nx + nu) * (F_FWD + (F_BWD_FULL if args.modules_student == 0 else 0))
-        cfg = {"workload": f"eval_BreastPathQ_SSL_CR.train step, per-GPU --batch_size {b} --mu {mu}: student {nx}+{nu}, teacher {nu} "
-                           f"({patches} distinct {hw}x{hw} uint8 patches/step/GPU), modules_student={args.modules_student}, Adam",
-               "global_batch_patches": patches * world, "parallelism": f"dp{world}", "backward": bwd,
-               "bn_sync": bool(args.bn_sync) if world > 1 else None, "aux_stream": bool(args.aux_stream)}
-    elif args.workload == "fwd":
-        n = 4 * b
-        ms, cs = build_nets(args, device)
-        ms.eval()
-        st = eng.bind(ms, cs)
-        x = synth_u8((n, 3, hw, hw), 1234 + rank, device)
-        patches = n
-
-        def step():
-            return st.forward((x,), train=False)
-        flops_step = n * F_FWD
-        cfg = {"workload": f"ResNet18 TripletNet_Finetune forward-only (eval BN folded), N={n} {hw}x{hw}", "parallelism": f"dp{world}"}
-    else:
-        B = 2 * b
-        ms, cs = build_nets(args, device, triplet=True)
-        ms.train()
-        st = eng.bind(ms, cs)
-        opt = torch.optim.SGD(list(ms.parameters()) + list(cs.parameters()), lr=0.01, momentum=0.9, weight_decay=wd, nesterov=True)
-        xs = [synth_u8((B, 3, hw, hw), 1234 + 10 * i + rank, device) for i in range(3)]
-        y = torch.randint(0, 6, (B,), generator=torch.Generator().manual_seed(5234 + rank)).to(device)
-        patches = 3 * B
-
-        def step():
-            r = eng.step_supervised(st, "ce", xs, y, train=True)
-            st.optimizer_step(opt)
-            return r
-        flops_step = 3 * B * (F_FWD + F_BWD_FULL)
-        cfg = {"workload": f"pretrain_BreastPathQ.train step (RSP), B={B} triplets {hw}x{hw}, SGD-Nesterov", "parallelism": f"dp{world}"}
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    step, patches, flops_step, cfg, keep = make_workload(args.workload, eng, args, device, rank, world)
+    dt = timed(step, args.warmup, args.steps, barrier)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = patches * world * args.steps / dt
+    crank, cworld, transport = eng.comm_info()
 
     out = {"metric": "images/sec (ResNet18 SSL_CR step, 256x256 bf16 synthetic patches; whole job)" if args.workload == "ssl_cr"
            else f"images/sec ({args.workload})",
@@ -215,25 +311,42 @@ def main():
            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": args.dtype, "data": "synthetic", "config": cfg,
            "per_gpu_images_per_s": round(value / world, 1),
-           "achieved_tflops_per_gpu_algorithmic": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2)}
+           "achieved_tflops_per_gpu_algorithmic": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
+           "ranks_seen": cworld, "collective_transport": transport}
 
     if rank == 0 and not args.no_roofline:
         # roofline leg: same steps again with every conv launch bracketed by HIP events on its own stream
         eng.profile(True)
-        for _ in range(max(2, min(5, args.steps))):
+        nprof = max(2, min(5, args.steps))
+        for _ in range(nprof):
             step()
         torch.cuda.synchronize()
         rows = eng.profile_table()          # per kernel template instance, sorted by total time
         eng.profile(False)
         peak = 2500.0 if args.dtype == "bf16" else 157.3
-        nprof = max(2, min(5, args.steps))
         hbm_rows = [r for r in rows if r["flops"] == 0]
         rows = [r for r in rows if r["flops"] > 0]
+        pmc = {}
+        if os.path.exists(os.path.join(ROOT, PMC_FILE)) and args.workload == "ssl_cr" and args.dtype == "bf16":
+            pmc = {e["kernel"]: e for e in json.load(open(os.path.join(ROOT, PMC_FILE)))["kernels"]}
+
+        def pmc_of(name):
+            for k, e in pmc.items():
+                if name.startswith(k) or k.startswith(name):
+                    return e
+            return None
 
         def roof(d):
+            e = pmc_of(d["name"])
             common = {"kernel": d["name"], "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
-                      "algorithmic_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 2), "traffic": None,
+                      "algorithmic_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 2),
+                      "traffic": round(e["traffic_bytes_per_launch"]) if e and e.get("traffic_bytes_per_launch") else None,
                       "time_share_of_step": round(d["ms"] / (ms_per_step * nprof), 3)}
+            if e:
+                # rocprofv3 --pmc passes over this same command (tools/pmc_step.sh), averaged over the kernel's launches of a step
+                common["pmc"] = {"source": PMC_FILE, "mfma_busy": e.get("mfma_busy"), "valu_per_mfma": e.get("valu_per_mfma"),
+                                 "traffic_over_algorithmic": round(e["traffic_bytes_per_launch"] / (d["bytes"] / d["launches"]), 3)
+                                 if e.get("traffic_bytes_per_launch") else None}
             if d["flops"] > 0:
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
                 return dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
@@ -248,28 +361,45 @@ def main():
             if hbm_rows and hbm_rows[0]["ms"] > d["ms"]:
                 out["roofline_note"] = ("by total time the HBM-bound bn_bwd_apply kernel edges out the largest conv kernel; both "
                                         "roofs are reported (roofline = MFMA kernel, roofline_hbm = that kernel)")
-            # HBM traffic of this kernel comes from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE), which
-            # cannot run inside this process: report the committed measurement of one instance beside its algorithmic bytes
-            pmc = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
-            if os.path.exists(pmc):
-                for e in json.load(open(pmc))["kernels"]:
-                    if e["match"] in d["name"]:
-                        # ratio = PMC traffic / algorithmic bytes over the shapes this kernel runs in the step, weighted by
-                        # the step's launch mix; the launches differ from the measured ones only in N (640 vs 448)
-                        out["roofline"]["traffic"] = round(e["ratio"] * out["roofline"]["algorithmic_mb_per_launch"] * 1e6)
-                        out["roofline"]["traffic_pmc"] = {
-                            "ratio": e["ratio"], "shapes": e["shapes"], "launch_mix": e["bench_mix"],
-                            "unit_of_traffic": "bytes per launch = ratio x algorithmic bytes of the average launch",
-                            "source": "profiles/r01_g_pmc_traffic.json"}
-                        break
-            out["conv_kernels"] = [{"kernel": r["name"], "launches_per_step": r["launches"] // nprof,
-                                    "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
-                                    "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
-                                    "ms_per_step": round(r["ms"] / nprof, 3)} for r in rows]
+            out["conv_kernels"] = []
+            for r in rows:
+                e = pmc_of(r["name"])
+                out["conv_kernels"].append({"kernel": r["name"], "launches_per_step": r["launches"] // nprof,
+                                            "avg_launch_us": round(r["ms"] * 1e3 / r["launches"], 2),
+                                            "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1),
+                                            "ms_per_step": round(r["ms"] / nprof, 3),
+                                            "mfma_busy": e.get("mfma_busy") if e else None})
             tot_ms = sum(r["ms"] for r in rows)
             tot_fl = sum(r["flops"] for r in rows)
             out["conv_all"] = {"tflops": round(tot_fl / (tot_ms * 1e-3) / 1e12, 1), "frac_of_peak": round(tot_fl / (tot_ms * 1e-3) / 1e12 / peak, 4),
                                "time_share_of_step": round(tot_ms / (ms_per_step * nprof), 3)}
+            if pmc:
+                busy = [(r["ms"], pmc_of(r["name"])) for r in rows]
+                busy = [(m, e["mfma_busy"]) for m, e in busy if e and e.get("mfma_busy") is not None]
+                if busy:
+                    out["conv_all"]["mfma_busy_time_weighted"] = round(sum(m * b for m, b in busy) / sum(m for m, _ in busy), 4)
+                    out["conv_all"]["mfma_busy_source"] = PMC_FILE
+
+    if rank == 0 and world == 1 and not args.no_also and args.workload == "ssl_cr" and args.dtype == "bf16":
+        # the other BASELINE.json configurations, same process, same box (short runs: they are records, not the headline)
+        also = {}
+        del keep
+
+        def rec(tag, wl, eng_, steps, warmup, **kw):
+            s, p, fl, c, k = make_workload(wl, eng_, args, device, rank, world, **kw)
+            t = timed(s, warmup, steps, barrier)
+            peak = 2500.0 if eng_ is eng else 157.3
+            also[tag] = {"images_per_s": round(p * steps / t, 1), "ms_per_step": round(t / steps * 1e3, 3), "steps": steps,
+                         "achieved_tflops_algorithmic": round(fl / (t / steps) / 1e12, 2),
+                         "frac_of_peak": round(fl / (t / steps) / 1e12 / peak, 4), "peak_tflops": peak, "workload": c["workload"]}
+        rec("forward_only_config2", "fwd", eng, 20, 5)
+        rec("rsp_config3", "rsp", eng, 10, 3)
+        rec("frozen_backbone_modules_student_60", "ssl_cr", eng, 10, 3, modules_student=60)
+        eng32 = E.Engine(device, "fp32")
+        rec("parity_mode_fp32", "ssl_cr", eng32, 4, 2)
+        also["parity_mode_fp32"]["note"] = ("exact-parity engine mode (v_mfma_f32_16x16x4_f32, fp32 storage): the mode that holds the "
+                                            "north-star 1e-3 against the reference goldens; peak = 157.3 TF fp32 matrix")
+        out["also"] = also
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "ssl_cr":
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
