@@ -22,6 +22,7 @@ extern "C" {
 
 #define SSLCR_F32 0
 #define SSLCR_BF16 1
+#define SSLCR_FP8 2   /* engine mode only (sslcr_create): bf16 storage and backward, fp8 e4m3 forward for the eligible 3x3 convs */
 
 int sslcr_version(void);
 const char* sslcr_last_error(void);
@@ -60,6 +61,29 @@ int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d);
 /* name of the kernel instance sslcr_conv2d would launch for this descriptor, spelled as rocprofv3 prints it (static string;
    lets tests and profiles tie a shape to the code path that serves it) */
 const char* sslcr_conv2d_kernel_name(int dtype, const sslcr_conv_desc* d);
+
+/* ---- fp8 (OCP e4m3) forward conv path: BASELINE config 5, eval_Camelyon_SSL_CR.py:33-157 "fp8 MFMA conv path".
+ *      Serves 3x3 / stride 1 / pad 1 convs with C % 128 == 0, K % 128 == 0 on 16x16-tileable maps (or 8x8 maps with N % 4 == 0):
+ *      ResNet18 layers 2-4.  x / y / residual are bf16 NHWC exactly as in sslcr_conv2d(SSLCR_BF16, ...) (in_scale / in_shift /
+ *      in_relu, bias, residual, relu, stats all honoured); the descriptor's `w` is ignored in favour of the e4m3 pack.
+ *      Quantisation: activations x * x_scale clamped to +-448, round-to-nearest-even, on the way into LDS; weights
+ *      w * w_scale[k] (power of two, amax -> (224, 448]) by sslcr_pack_conv_fp8; fp32 accumulate; result * w_dequant[k] / x_scale. */
+typedef struct sslcr_fp8_desc {
+  const uint8_t* w8;        /* [K][3][3][C] e4m3 */
+  const float* w_dequant;   /* [K]: 1 / w_scale[k] */
+  float x_scale;            /* per-tensor activation scale (> 0); 1 = activations used as they are (post-BatchNorm values sit in
+                               e4m3's normal range [2^-6, 448]) */
+} sslcr_fp8_desc;
+int sslcr_conv2d_fp8(const sslcr_conv_desc* d, const sslcr_fp8_desc* q, void* stream);
+int sslcr_conv2d_fp8_partial_rows(const sslcr_conv_desc* d);      /* rows of d->stats the fp8 kernel writes; 0 = shape not served */
+typedef struct sslcr_pack_fp8_desc {
+  const float* w;           /* [K][C][3][3] fp32 (PyTorch layout) */
+  uint8_t* w8;              /* [K][3][3][C] e4m3 out */
+  float* w_dequant;         /* [K] out */
+  const float* gamma; const float* beta; const float* rmean; const float* rvar; float eps; float* bias_out;   /* optional: fold BatchNorm (eval) */
+  int K, C;
+} sslcr_pack_fp8_desc;
+int sslcr_pack_conv_fp8(const sslcr_pack_fp8_desc* d, void* stream);
 
 /* ---- conv2d weight gradient (autograd wgrad of the same convs) */
 typedef struct sslcr_wgrad_desc {

@@ -62,6 +62,10 @@ WeakAugDesc = _S("WeakAugDesc", [("src", vp), ("dst", vp), ("params", vp)] +
 PackDesc = _S("PackDesc", [("w", vp), ("w_fwd", vp), ("w_dgrad", vp), ("gamma", vp), ("beta", vp), ("rmean", vp),
                            ("rvar", vp), ("eps", f32), ("bias_out", vp)] + [(k, i32) for k in ("K", "C", "R", "S", "dgrad_flip")])
 
+Fp8Desc = _S("Fp8Desc", [("w8", vp), ("w_dequant", vp), ("x_scale", f32)])
+PackFp8Desc = _S("PackFp8Desc", [("w", vp), ("w8", vp), ("w_dequant", vp), ("gamma", vp), ("beta", vp), ("rmean", vp), ("rvar", vp),
+                                 ("eps", f32), ("bias_out", vp), ("K", i32), ("C", i32)])
+
 # symbol -> (restype, argtypes); every symbol include/sslcr.h declares
 P = C.POINTER
 SIGNATURES = {
@@ -70,6 +74,9 @@ SIGNATURES = {
     "sslcr_conv2d": (i32, [i32, P(ConvDesc), vp]),
     "sslcr_conv2d_partial_rows": (i32, [P(ConvDesc)]),
     "sslcr_conv2d_kernel_name": (C.c_char_p, [i32, P(ConvDesc)]),
+    "sslcr_conv2d_fp8": (i32, [P(ConvDesc), P(Fp8Desc), vp]),
+    "sslcr_conv2d_fp8_partial_rows": (i32, [P(ConvDesc)]),
+    "sslcr_pack_conv_fp8": (i32, [P(PackFp8Desc), vp]),
     "sslcr_conv2d_wgrad": (i32, [i32, P(WgradDesc), vp]),
     "sslcr_probe_tr16": (i32, [vp, vp, vp, vp]),
     "sslcr_stem_conv": (i32, [i32, P(StemDesc), vp]),

@@ -45,6 +45,19 @@ int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream) {
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d) { return d ? conv_partials_rows(*d) : -1; }
 const char* sslcr_conv2d_kernel_name(int dtype, const sslcr_conv_desc* d) { return d ? conv_kernel_name(dtype, *d) : ""; }
 
+int sslcr_conv2d_fp8(const sslcr_conv_desc* d, const sslcr_fp8_desc* q, void* stream) {
+  NEED(d && q && d->x && d->y && q->w8 && q->w_dequant, "null tensor");
+  NEED(q->x_scale > 0.f, "x_scale must be positive");
+  NEED(conv_fp8_mode(*d) != 0, "shape not served by the fp8 kernel (3x3/1, C % 128, K % 128, 16x16-tileable or 8x8 with N % 4)");
+  return check(launch_conv_fp8(*d, *q, (hipStream_t)stream), "conv2d_fp8");
+}
+int sslcr_conv2d_fp8_partial_rows(const sslcr_conv_desc* d) { return (d && conv_fp8_mode(*d)) ? conv_fp8_rows(*d) : 0; }
+int sslcr_pack_conv_fp8(const sslcr_pack_fp8_desc* d, void* stream) {
+  NEED(d && d->w && d->w8 && d->w_dequant && d->K > 0 && d->C > 0, "args");
+  NEED(!d->gamma || (d->beta && d->rmean && d->rvar), "BatchNorm fold needs gamma, beta, running mean and var");
+  return check(launch_pack_fp8(*d, (hipStream_t)stream), "pack_conv_fp8");
+}
+
 int sslcr_conv2d_wgrad(int dtype, const sslcr_wgrad_desc* d, void* stream) {
   DT_OK(dtype);
   NEED(d && d->x && d->dy && d->dw, "null tensor");

@@ -70,6 +70,10 @@ struct ConvL {
   int cin = 0, cout = 0, k = 0, stride = 1, pad = 0, pidx = -1;
   void *w_fwd = nullptr, *w_dg = nullptr, *w_fold = nullptr;
   float* b_fold = nullptr;
+  // fp8 engine mode (SSLCR_FP8): e4m3 shadow packs + per-kout dequant factors of the train / eval-folded filters, for the
+  // convs the fp8 kernel serves (3x3 stride 1, cin and cout multiples of 128: layers 2-4)
+  uint8_t *w8_fwd = nullptr, *w8_fold = nullptr;
+  float *dq_fwd = nullptr, *dq_fold = nullptr;
 };
 struct BnL {
   int C = 0, pg = -1, pb = -1, bidx = -1;
@@ -143,6 +147,7 @@ struct sslcr_vcomm {
 struct sslcr_ctx {
   Profiler prof;
   int device = 0, dtype = 0;
+  int fp8 = 0;                    // SSLCR_FP8: dtype stays bf16 (storage, backward); eligible forward convs run the e4m3 kernel
   sslcr_vcomm* vcomm = nullptr;   // set instead of comm / comm_g by sslcr_comm_init_virtual
   ncclComm_t comm = nullptr;      // BatchNorm-sum all-reduces, only ever used on the caller's (compute) stream
   ncclComm_t comm_g = nullptr;    // gradient buckets, only ever used on comm_stream (one communicator per stream, like
@@ -283,6 +288,31 @@ hipError_t prof_conv(sslcr_ctx* c, int dt, const ConvArgs& a, hipStream_t st) {
   c->prof.rec[0].push_back(r);
   return e;
 }
+inline bool fp8_layer(const sslcr_ctx* c, const ConvL& L) {
+  return c->fp8 && L.k == 3 && L.stride == 1 && L.cin % 128 == 0 && L.cout % 128 == 0;
+}
+// forward conv of layer L (folded = eval pack): the fp8 kernel where the mode, the layer and the shape allow it, else the
+// engine dtype's kernel
+inline bool use_fp8(const sslcr_ctx* c, const ConvL& L, const ConvArgs& a) { return fp8_layer(c, L) && L.w8_fwd && conv_fp8_mode(a) != 0; }
+hipError_t prof_conv_fwd(sslcr_ctx* c, int dt, const ConvArgs& a, const ConvL& L, bool folded, hipStream_t st) {
+  if (!use_fp8(c, L, a)) return prof_conv(c, dt, a, st);
+  Fp8Args q;
+  q.w8 = folded ? L.w8_fold : L.w8_fwd;
+  q.w_dequant = folded ? L.dq_fold : L.dq_fwd;
+  q.x_scale = 1.0f;       // post-BatchNorm activations sit in e4m3's normal range [2^-6, 448] as they are (include/sslcr.h)
+  if (!c->prof.on) return launch_conv_fp8(a, q, st);
+  ProfRec r;
+  r.e0 = c->prof.get(); r.e1 = c->prof.get();
+  const double M = (double)a.N * a.PH * a.PW;
+  r.flops = 2.0 * M * a.K * a.C * 9.0;
+  r.bytes = ((double)a.N * a.H * a.W * a.C + M * a.K * (a.residual ? 2.0 : 1.0)) * 2.0 + (double)a.K * 9.0 * a.C;
+  r.name = conv_fp8_name(a);
+  (void)hipEventRecord(r.e0, st);
+  hipError_t e = launch_conv_fp8(a, q, st);
+  (void)hipEventRecord(r.e1, st);
+  c->prof.rec[0].push_back(r);
+  return e;
+}
 hipError_t prof_wgrad(sslcr_ctx* c, int dt, const WgradArgs& a, hipStream_t st) {
   if (!c->prof.on) return launch_wgrad(dt, a, st);
   ProfRec r;
@@ -369,6 +399,10 @@ int alloc_shadow(sslcr_net* n) {
     c.take(wbytes);                     // w_dg
     c.take(wbytes);                     // w_fold
     c.take(L.cout * sizeof(float));     // b_fold
+    if (fp8_layer(n->ctx, L)) {         // w8_fwd, w8_fold, dq_fwd, dq_fold
+      c.take((size_t)L.cout * 9 * L.cin); c.take((size_t)L.cout * 9 * L.cin);
+      c.take(L.cout * sizeof(float)); c.take(L.cout * sizeof(float));
+    }
     offs.push_back({&L, o});
   };
   add(n->stem);
@@ -386,6 +420,12 @@ int alloc_shadow(sslcr_net* n) {
     L.w_dg = base + wbytes;
     L.w_fold = base + 2 * wbytes;
     L.b_fold = (float*)(base + 3 * wbytes);
+    if (fp8_layer(n->ctx, L)) {
+      const size_t bb = (L.cout * sizeof(float) + 255) & ~(size_t)255, w8 = ((size_t)L.cout * 9 * L.cin + 255) & ~(size_t)255;
+      char* q = base + 3 * wbytes + bb;
+      L.w8_fwd = (uint8_t*)q; L.w8_fold = (uint8_t*)(q + w8);
+      L.dq_fwd = (float*)(q + 2 * w8); L.dq_fold = (float*)(q + 2 * w8 + bb);
+    }
   }
   return 0;
 }
@@ -411,6 +451,20 @@ int pack_conv_layer(sslcr_net* n, ConvL& L, const BnL& bn, int mode, hipStream_t
     a.rmean = n->bn_rm[bn.bidx]; a.rvar = n->bn_rv[bn.bidx];
     a.bias_out = L.b_fold;
     TRY(stem ? launch_pack_stem(dt, a, st) : launch_pack_conv(dt, a, st));
+  }
+  if (L.w8_fwd) {
+    PackFp8Args f;
+    memset(&f, 0, sizeof(f));
+    f.w = n->params[L.pidx]; f.K = L.cout; f.C = L.cin; f.eps = 1e-5f;
+    if (mode & 1) {
+      f.w8 = L.w8_fwd; f.w_dequant = L.dq_fwd;
+      TRY(launch_pack_fp8(f, st));
+    }
+    if (mode & 2) {
+      f.w8 = L.w8_fold; f.w_dequant = L.dq_fold;
+      f.gamma = n->params[bn.pg]; f.beta = n->params[bn.pb]; f.rmean = n->bn_rm[bn.bidx]; f.rvar = n->bn_rv[bn.bidx];
+      TRY(launch_pack_fp8(f, st));        // (the folded bias is the bf16 pack's b_fold)
+    }
   }
   return 0;
 }
@@ -451,8 +505,8 @@ ConvArgs conv_args(const ConvL& L, const void* x, const void* w, void* y, int N,
   return a;
 }
 
-int ensure_partials(sslcr_ctx* c, const ConvArgs& a, float** out, int* rows) {
-  *rows = conv_partials_rows(a);
+int ensure_partials(sslcr_ctx* c, const ConvArgs& a, float** out, int* rows, bool fp8 = false) {
+  *rows = fp8 ? conv_fp8_rows(a) : conv_partials_rows(a);
   TRYI(c->partials.ensure((size_t)*rows * 2 * a.K * sizeof(float)));
   *out = (float*)c->partials.p;
   return 0;
@@ -544,15 +598,15 @@ int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f3
     const int oh = d.lh[i], ow = d.lw[i];
     float* part; int rows;
     ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fwd, ps.blk[i].raw1, N, xh, xw);
-    TRYI(ensure_partials(c, a1, &part, &rows));
+    TRYI(ensure_partials(c, a1, &part, &rows, use_fp8(c, B.c1, a1)));
     a1.stats = part;
-    TRY(prof_conv(c, dt,a1, st));
+    TRY(prof_conv_fwd(c, dt, a1, B.c1, false, st));
     TRYI(finalize_bn(n, B.b1, part, rows, (double)N * oh * ow, ps.bn[B.b1.bidx], replay, st));
     ConvArgs a2 = conv_args(B.c2, ps.blk[i].raw1, B.c2.w_fwd, ps.blk[i].raw2, N, oh, ow);
     a2.in_scale = ps.bn[B.b1.bidx].scale; a2.in_shift = ps.bn[B.b1.bidx].shift; a2.in_relu = 1;
-    TRYI(ensure_partials(c, a2, &part, &rows));
+    TRYI(ensure_partials(c, a2, &part, &rows, use_fp8(c, B.c2, a2)));
     a2.stats = part;
-    TRY(prof_conv(c, dt,a2, st));
+    TRY(prof_conv_fwd(c, dt, a2, B.c2, false, st));
     TRYI(finalize_bn(n, B.b2, part, rows, (double)N * oh * ow, ps.bn[B.b2.bidx], replay, st));
     BnActArgs e;
     memset(&e, 0, sizeof(e));
@@ -610,7 +664,7 @@ int backbone_forward_eval(sslcr_net* n, const void* x, int in_f32, int N, int H,
     const int oh = d.lh[i], ow = d.lw[i];
     ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fold, t1, N, xh, xw);
     a1.bias = B.c1.b_fold; a1.relu = 1;
-    TRY(prof_conv(c, dt,a1, st));
+    TRY(prof_conv_fwd(c, dt, a1, B.c1, true, st));
     const void* res = X;
     if (B.has_ds) {
       ConvArgs ad = conv_args(B.ds, X, B.ds.w_fold, td, N, xh, xw);
@@ -620,7 +674,7 @@ int backbone_forward_eval(sslcr_net* n, const void* x, int in_f32, int N, int H,
     }
     ConvArgs a2 = conv_args(B.c2, t1, B.c2.w_fold, Y, N, oh, ow);
     a2.bias = B.c2.b_fold; a2.residual = res; a2.relu = 1;
-    TRY(prof_conv(c, dt,a2, st));
+    TRY(prof_conv_fwd(c, dt, a2, B.c2, true, st));
     xi = (xi + 3) & 3; xh = oh; xw = ow;
   }
   TRY(launch_avgpool_fwd(dt, base + o_buf[xi], E, N, xh * xw, 512, st));
@@ -1042,10 +1096,10 @@ int net_backward(sslcr_net* n, const float* dlogits, hipStream_t st) {
 extern "C" {
 
 int sslcr_create(sslcr_ctx** out, int device, int dtype) {
-  if (!out || (dtype != SSLCR_F32 && dtype != SSLCR_BF16)) return fail("sslcr_create: invalid argument");
+  if (!out || (dtype != SSLCR_F32 && dtype != SSLCR_BF16 && dtype != SSLCR_FP8)) return fail("sslcr_create: invalid argument");
   TRY(hipSetDevice(device));
   sslcr_ctx* c = new sslcr_ctx();
-  c->device = device; c->dtype = dtype;
+  c->device = device; c->dtype = dtype == SSLCR_FP8 ? SSLCR_BF16 : dtype; c->fp8 = dtype == SSLCR_FP8;
   if (c->small.ensure(32 * 2 * 512 * sizeof(double) + 2 * 2 * 512 * sizeof(double) + 2 * 512 * sizeof(float)) != 0) { delete c; return -1; }
   c->bn_stage = (double*)c->small.p;
   c->bn_sums = c->bn_stage + 32 * 2 * 512;        // two [2][C] slots (bn2 + projection BatchNorm of a block share an all-reduce)
@@ -1356,6 +1410,18 @@ int sslcr_net_optimizer_step(sslcr_net* n, const sslcr_opt_desc* o, float* const
   if (n->opt_packs_all) {
     // every block conv's shadow weights were rewritten with the update; only the stem's (its own K order) are left
     TRYI(pack_conv_layer(n, n->stem, n->bn0, 1, st));
+    if (n->ctx->fp8) {                 // e4m3 train packs of the updated filters (the bf16 packs were written by the update itself)
+      for (int b = 0; b < 8; ++b) {
+        ConvL* Ls[2] = {&n->blocks[b].c1, &n->blocks[b].c2};
+        for (ConvL* L : Ls) {
+          if (!L->w8_fwd) continue;
+          PackFp8Args f;
+          memset(&f, 0, sizeof(f));
+          f.w = n->params[L->pidx]; f.K = L->cout; f.C = L->cin; f.eps = 1e-5f; f.w8 = L->w8_fwd; f.w_dequant = L->dq_fwd;
+          TRY(launch_pack_fp8(f, st));
+        }
+      }
+    }
     n->packed_train = true;
   }
   return 0;

@@ -19,6 +19,8 @@ using LossArgs = sslcr_loss_desc;
 using TensorDesc = sslcr_tensor_desc;
 using OptArgs = sslcr_opt_desc;
 using PackArgs = sslcr_pack_desc;
+using Fp8Args = sslcr_fp8_desc;
+using PackFp8Args = sslcr_pack_fp8_desc;
 
 // conv_igemm.hip
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st);
@@ -44,6 +46,12 @@ int conv_dma_bp(int dtype, const ConvArgs& a);
 int conv_dma_rows(const ConvArgs& a, int bp);
 hipError_t launch_conv_dma(int dtype, const ConvArgs& a, int bp, hipStream_t st);
 const char* conv_dma_name(int dtype, int bp);
+// conv_fp8.hip
+int conv_fp8_mode(const ConvArgs& a);
+int conv_fp8_rows(const ConvArgs& a);
+const char* conv_fp8_name(const ConvArgs& a);
+hipError_t launch_conv_fp8(const ConvArgs& a, const Fp8Args& q, hipStream_t st);
+hipError_t launch_pack_fp8(const PackFp8Args& a, hipStream_t st);
 // conv_wgrad.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 int wgrad_halo_tw(const WgradArgs& a);

@@ -11,7 +11,7 @@ import torch
 from . import _lib as L
 from .net import Classifier, FinetuneResNet, TripletNet, TripletNet_Finetune, unwrap
 
-_DTYPES = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
+_DTYPES = {"fp32": 0, "f32": 0, "float32": 0, "bf16": 1, "bfloat16": 1, "fp8": 2}     # fp8: bf16 engine + e4m3 forward convs (config 5)
 
 SslcrNetDesc = type("SslcrNetDesc", (C.Structure,), {"_fields_": [
     ("params", C.POINTER(C.c_void_p)), ("nparams", C.c_int), ("bn_running_mean", C.POINTER(C.c_void_p)),

@@ -70,6 +70,42 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
     return (y, stats) if want_stats else y
 
 
+def pack_conv_fp8(w_kcrs, *, bn=None, eps=1e-5):
+    """PyTorch [K,C,3,3] fp32 -> (w8 [K,3,3,C] uint8 = OCP e4m3 bits, w_dequant [K] fp32, bias [K] | None): per-output-channel
+    power-of-two scale (amax -> (224, 448]); bn = (gamma, beta, running_mean, running_var) folds eval-mode BatchNorm."""
+    _chk(w_kcrs)
+    K, C, R, S = w_kcrs.shape
+    assert R == 3 and S == 3
+    dev = w_kcrs.device
+    w8 = torch.empty((K, 3, 3, C), dtype=torch.uint8, device=dev)
+    dq = torch.empty(K, dtype=torch.float32, device=dev)
+    bias = torch.empty(K, dtype=torch.float32, device=dev) if bn is not None else None
+    g, b, rm, rv = bn if bn is not None else (None, None, None, None)
+    d = L.PackFp8Desc(L.ptr(w_kcrs), L.ptr(w8), L.ptr(dq), L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), eps, L.ptr(bias), K, C)
+    L.check(L.lib().sslcr_pack_conv_fp8(d, L.stream_ptr()))
+    return w8, dq, bias
+
+
+def conv2d_fp8(x, w8, w_dequant, *, x_scale=1.0, in_scale=None, in_shift=None, in_relu=False, bias=None, residual=None, relu=False,
+               want_stats=False):
+    """fp8 (e4m3) forward conv 3x3 / stride 1 / pad 1: x bf16 NHWC [N,H,W,C], w8 [K,3,3,C] e4m3 bits -> y bf16 NHWC (+ stats)."""
+    _chk(x, w8, w_dequant, in_scale, in_shift, bias, residual)
+    assert x.dtype == torch.bfloat16 and w8.dtype == torch.uint8
+    N, H, W, C = x.shape
+    K = w8.shape[0]
+    y = torch.empty((N, H, W, K), dtype=torch.bfloat16, device=x.device)
+    d = L.ConvDesc(L.ptr(x), None, L.ptr(y), L.ptr(in_scale), L.ptr(in_shift), L.ptr(bias), L.ptr(residual), None,
+                   N, H, W, C, K, 3, 3, 1, 1, H, W, H, W, 1, 0, int(in_relu), int(relu), 0, 0, 0, 0, 0)
+    q = L.Fp8Desc(L.ptr(w8), L.ptr(w_dequant), float(x_scale))
+    stats = None
+    if want_stats:
+        rows = L.lib().sslcr_conv2d_fp8_partial_rows(d)
+        stats = torch.empty((rows, 2, K), dtype=torch.float32, device=x.device)
+        d.stats = L.ptr(stats)
+    L.check(L.lib().sslcr_conv2d_fp8(d, q, L.stream_ptr()))
+    return (y, stats) if want_stats else y
+
+
 def conv2d_wgrad(x, dy, dw, R, S, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, seg_images=0):
     """accumulate dW [K,R,S,C] fp32 += wgrad(x NHWC, dy NHWC).  seg_images > 0: in_scale / in_shift are [N // seg_images, C],
     one producer BatchNorm per segment of seg_images images."""

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 3 --warmup 2 --no-roofline --no-cpu-baseline --no-also"
 i=0
 for s in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
-  timeout 600 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $out/pass$i -o pmc -- $CMD > $out/pass$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $s --kernel-trace --output-format csv -d $out/pass$i -o pmc -- $CMD > $out/pass$i.log 2>&1
   i=$((i+1))
 done
 cd $R

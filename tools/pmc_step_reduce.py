@@ -1,7 +1,10 @@
 """reduce the rocprofv3 --pmc passes of tools/pmc_step.sh to one JSON: per kernel template instance, averaged over its launches.
 
-  mfma_busy   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)   matrix-pipe busy cycles over the cycles the dispatch
-                occupies the GPU (GRBM_GUI_ACTIVE of the same dispatch, same pass) -- the MfmaUtil definition
+  mfma_busy   = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)   matrix-pipe busy cycles (summed over SIMDs) over
+                the cycles the dispatch occupies the GPU -- the MfmaUtil definition.  rocprofv3 reports GRBM_GUI_ACTIVE summed
+                over the 8 XCDs (checked against the same dispatch's timestamps: 2 431 424 cycles in 139.6 us = 17.4 GHz =
+                8 x 2.18 GHz), hence the / 8; SQ_VALU_MFMA_BUSY_CYCLES = 16 cycles per v_mfma_f32_16x16x32_bf16, i.e. the time the
+                instruction needs at the 2.5 PF peak, so mfma_busy is achieved / peak at the clock the kernel actually ran at
   mfma_busy_wave_life = the round-1 definition (busy cycles per SIMD over 4 x SQ_WAVE_CYCLES / SQ_WAVES), kept for comparison
   traffic_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024   FETCH_SIZE doubled: the gfx950 wide-read correction of
                 /opt/skills/guides/MI355X_MICROARCH.md (HBM section); WRITE_SIZE as reported (KiB)
@@ -26,7 +29,7 @@ for f in glob.glob(out + "/pass*/**/pmc_counter_collection.csv", recursive=True)
         for k, v in c.items():
             agg[name][k].append(v)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE", 0) > 0:
-            agg[name]["_busy"].append(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"]))
+            agg[name]["_busy"].append(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * c["GRBM_GUI_ACTIVE"] / 8.0))
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("SQ_WAVES", 0) > 0 and c.get("SQ_WAVE_CYCLES", 0) > 0:
             agg[name]["_busy_wl"].append((c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (4.0 * c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"]))
 
@@ -47,7 +50,7 @@ for name, c in agg.items():
         e["valu_per_mfma"] = round(mean(c["SQ_INSTS_VALU"]) / mean(c["SQ_INSTS_MFMA"]), 3)
         e["mfma_insts_per_launch"] = round(mean(c["SQ_INSTS_MFMA"]))
     if c.get("GRBM_GUI_ACTIVE"):
-        e["gui_active_cycles"] = round(mean(c["GRBM_GUI_ACTIVE"]))
+        e["gui_active_cycles"] = round(mean(c["GRBM_GUI_ACTIVE"]) / 8.0)
     if c.get("FETCH_SIZE") and c.get("WRITE_SIZE"):
         e["fetch_kib"] = round(mean(c["FETCH_SIZE"]), 1)
         e["write_kib"] = round(mean(c["WRITE_SIZE"]), 1)
@@ -56,7 +59,7 @@ for name, c in agg.items():
 kernels.sort(key=lambda e: -(e.get("gui_active_cycles", 0) * e["dispatches_measured"]))
 doc = {"note": "rocprofv3 --pmc passes (counters only, --kernel-trace) over `python bench.py --steps 3 --warmup 2 --no-roofline "
                "--no-cpu-baseline --no-also`: per kernel template instance, mean over ALL its launches of the run (the launch mix of "
-               "the benchmark step itself).  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE); "
+               "the benchmark step itself).  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); "
                "traffic_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 wide-read correction on FETCH_SIZE).",
        "kernels": kernels}
 json.dump(doc, open(out + "/pmc_step.json", "w"), indent=1)
