@@ -73,6 +73,10 @@ typedef struct sslcr_fp8_desc {
   const float* w_dequant;   /* [K]: 1 / w_scale[k] */
   float x_scale;            /* per-tensor activation scale (> 0); 1 = activations used as they are (post-BatchNorm values sit in
                                e4m3's normal range [2^-6, 448]) */
+  const float* x_scale_dev; /* optional device float: read instead of x_scale (delayed scaling without a host sync) */
+  float* amax_out;          /* optional device float (>= 0 on entry): atomically raised to max |transformed activation| seen by this
+                               launch, before scaling and clamping -- the engine turns it into the NEXT step's x_scale
+                               (scale = 2^floor(log2(448 / (2 amax))): a factor 2 of headroom), the delayed-scaling recipe */
 } sslcr_fp8_desc;
 int sslcr_conv2d_fp8(const sslcr_conv_desc* d, const sslcr_fp8_desc* q, void* stream);
 int sslcr_conv2d_fp8_partial_rows(const sslcr_conv_desc* d);      /* rows of d->stats the fp8 kernel writes; 0 = shape not served */

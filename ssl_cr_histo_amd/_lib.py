@@ -62,7 +62,7 @@ WeakAugDesc = _S("WeakAugDesc", [("src", vp), ("dst", vp), ("params", vp)] +
 PackDesc = _S("PackDesc", [("w", vp), ("w_fwd", vp), ("w_dgrad", vp), ("gamma", vp), ("beta", vp), ("rmean", vp),
                            ("rvar", vp), ("eps", f32), ("bias_out", vp)] + [(k, i32) for k in ("K", "C", "R", "S", "dgrad_flip")])
 
-Fp8Desc = _S("Fp8Desc", [("w8", vp), ("w_dequant", vp), ("x_scale", f32)])
+Fp8Desc = _S("Fp8Desc", [("w8", vp), ("w_dequant", vp), ("x_scale", f32), ("x_scale_dev", vp), ("amax_out", vp)])
 PackFp8Desc = _S("PackFp8Desc", [("w", vp), ("w8", vp), ("w_dequant", vp), ("gamma", vp), ("beta", vp), ("rmean", vp), ("rvar", vp),
                                  ("eps", f32), ("bias_out", vp), ("K", i32), ("C", i32)])
 

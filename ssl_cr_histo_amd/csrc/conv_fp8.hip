@@ -48,7 +48,8 @@ __global__ __launch_bounds__(512) void conv3x3_fp8_kernel(const ConvArgs a, cons
   constexpr int HH = TH + 2, HWD = TW + 2;
   constexpr int HP = NI * HH * HWD;               // 324 or 400 halo pixels
   constexpr int NLD = (HP * 16 + NT - 1) / NT;    // 16-byte (8 x bf16) staging loads per thread and stage: 11 or 13
-  constexpr int BATCH = (NLD + 6) / 7;            // ... issued in seven batches under taps 0..6, converted + written two taps later
+  constexpr int HD = 1;                           // taps between the request of a halo batch and its conversion
+  constexpr int BATCH = (NLD + 8 - HD) / (9 - HD); // ... issued in 9 - HD batches under taps 0 .., converted + written HD taps later
   constexpr int WLD = BKO * 8 / NT;               // 16-byte weight loads per thread and tap: 2
   constexpr int HBUF = ((HP * 128 + 1023) / 1024) * 1024, WBUF = BKO * 128;
   // LDS: the fp8 halo is DOUBLE-buffered (the next stage is written while this one is read, and the staging registers live
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(512) void conv3x3_fp8_kernel(const ConvArgs a, cons
   const int tiles_w = a.W / TW, tiles_h = a.H / TH;
   const int k0 = blockIdx.y * BKO;
   constexpr bool xform = XF;
-  const float xs = q.x_scale;
+  const float xs = q.x_scale_dev ? *q.x_scale_dev : q.x_scale;
+  float amax = 0.f;                                // of the transformed activations this thread converts, in scaled units
   if (xform)
     for (int c = tid; c < a.C; c += NT) { s_scale[c] = a.in_scale[c] * xs; s_shift[c] = a.in_shift[c] * xs; }
 
@@ -128,6 +130,13 @@ __global__ __launch_bounds__(512) void conv3x3_fp8_kernel(const ConvArgs a, cons
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] *= xs;
+    }
+    {   // amax for delayed scaling, tracked unconditionally (no branch in the tap loop; padding pixels and, with ReLU, the negative
+        // side are included: harmless headroom).  The accumulate is an inline v_max_f32: written as fmaxf() the compiler
+        // restructured the staging code around the loop-carried value and spilled ~100 registers instead of ~20.
+      const float m = fmaxf(fmaxf(fmaxf(fabsf(f[0]), fabsf(f[1])), fmaxf(fabsf(f[2]), fabsf(f[3]))),
+                            fmaxf(fmaxf(fabsf(f[4]), fabsf(f[5])), fmaxf(fabsf(f[6]), fabsf(f[7]))));
+      asm volatile("v_max_f32 %0, %0, %1" : "+v"(amax) : "v"(m));
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_fmed3f(f[e], lo_clamp, 448.f);     // ReLU and the e4m3 range in one instruction
@@ -214,8 +223,8 @@ __global__ __launch_bounds__(512) void conv3x3_fp8_kernel(const ConvArgs a, cons
     // the fragment addresses (pixel base + swizzled unit + tap immediate) are summed per read: as stage-loop invariants all 24
     // (pixel group, filter column, lo / hi) sums were kept in registers and spilled
     asm volatile("" : "+v"(pbase[0]), "+v"(pbase[1]), "+v"(pbase[2]), "+v"(pbase[3]));
-    u32x4_t hq[3][BATCH];
-    int hsrc[3][BATCH];
+    u32x4_t hq[HD + 1][BATCH];
+    int hsrc[HD + 1][BATCH];
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int j = s * 9 + tap;
@@ -230,14 +239,14 @@ __global__ __launch_bounds__(512) void conv3x3_fp8_kernel(const ConvArgs a, cons
       u32x4_t (&wold)[WLD] = wq[tap & 1];
       if (tap == 8) store_w_from(wold, (j + 2) % 3);
       if (tap + 3 < 9) load_w_to(wnew, slab, tap + 3); else load_w_to(wnew, pslab, tap + 3 - 9);
-      if (tap < 7) {                               // next stage's halo, batch `tap`: requested now, converted two taps later
+      if (tap < 9 - HD) {                          // next stage's halo, batch `tap`: requested now, converted HD taps later
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
           const int i = tap * BATCH + b;
           if (i < NLD) {
             const int src = src_of(hp_of(i), nn0, nh0, nw0);
-            hsrc[tap % 3][b] = src;
-            hq[tap % 3][b] = load_chunk(src, pslab);
+            hsrc[tap % (HD + 1)][b] = src;
+            hq[tap % (HD + 1)][b] = load_chunk(src, pslab);
           }
         }
       }
@@ -263,11 +272,11 @@ __global__ __launch_bounds__(512) void conv3x3_fp8_kernel(const ConvArgs a, cons
         }
       }
       // (no scheduling fence)
-      if (tap >= 2) {                              // batch tap-2 of the next halo: fp8 into the OTHER halo buffer
+      if (tap >= HD) {                             // batch tap-HD of the next halo: fp8 into the OTHER halo buffer
 #pragma unroll
         for (int b = 0; b < BATCH; ++b) {
-          const int i = (tap - 2) * BATCH + b;
-          if (i < NLD) store_chunk(hnext, hp_of(i), hsrc[(tap - 2) % 3][b], hq[(tap - 2) % 3][b]);
+          const int i = (tap - HD) * BATCH + b;
+          if (i < NLD) store_chunk(hnext, hp_of(i), hsrc[(tap - HD) % (HD + 1)][b], hq[(tap - HD) % (HD + 1)][b]);
         }
       }
       if (tap != 8) store_w_from(wold, (j + 2) % 3);
@@ -335,6 +344,12 @@ __global__ __launch_bounds__(512) void conv3x3_fp8_kernel(const ConvArgs a, cons
     for (int t = 0; t < TK; ++t)
 #pragma unroll
       for (int p = 0; p < TP; ++p) acc[t][p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  if (q.amax_out) {
+    float m = amax / xs;
+    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+    m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(q.amax_out), __float_as_uint(m));     // non-negative floats order like their bits
   }
 }
 
@@ -423,6 +438,23 @@ __global__ __launch_bounds__(256) void pack_fp8_kernel(const PackFp8Args a) {
     a.w_dequant[k] = 1.f / scale;
     if (a.gamma && a.bias_out) a.bias_out[k] = a.beta[k] - a.rmean[k] * f;
   }
+}
+
+// delayed scaling: slots [n][2] = {x_scale, amax seen since the last update}: scale <- 2^floor(log2(448 / (2 amax))), amax <- 0
+__global__ void fp8_scale_update_kernel(float* slots, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float m = slots[2 * i + 1];
+  if (m > 0.f && m < 3.0e38f) {
+    int e;
+    (void)frexpf(224.f / m, &e);
+    slots[2 * i] = fminf(fmaxf(ldexpf(1.f, e - 1), 1.0f / 65536.f), 65536.f);
+  }
+  slots[2 * i + 1] = 0.f;
+}
+hipError_t launch_fp8_scale_update(float* slots, int n, hipStream_t st) {
+  hipLaunchKernelGGL(fp8_scale_update_kernel, dim3((n + 63) / 64), dim3(64), 0, st, slots, n);
+  return hipGetLastError();
 }
 
 hipError_t launch_pack_fp8(const PackFp8Args& a, hipStream_t st) {

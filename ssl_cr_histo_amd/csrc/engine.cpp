@@ -74,6 +74,7 @@ struct ConvL {
   // convs the fp8 kernel serves (3x3 stride 1, cin and cout multiples of 128: layers 2-4)
   uint8_t *w8_fwd = nullptr, *w8_fold = nullptr;
   float *dq_fwd = nullptr, *dq_fold = nullptr;
+  float* f8s = nullptr;     // delayed activation scaling: {x_scale, amax} of the train forward, {x_scale, amax} of the eval forward
 };
 struct BnL {
   int C = 0, pg = -1, pb = -1, bidx = -1;
@@ -186,7 +187,9 @@ struct sslcr_net {
   ConvL stem;
   BnL bn0;
   BlockL blocks[8];
-  DevBuf shadow, grads, heads, descs, chunks;
+  DevBuf shadow, grads, heads, descs, chunks, f8buf;
+  float* f8slots = nullptr;       // [n8][2] = {x_scale, amax since the last update}: two slots (train, eval) per fp8 conv, see ConvL::f8s
+  int n8 = 0;
   int nchunks = 0;
   bool opt_packs_all = false;     // the optimizer work list rewrites every non-stem conv's train-mode shadow weights
   size_t grad_count = 0;
@@ -299,7 +302,11 @@ hipError_t prof_conv_fwd(sslcr_ctx* c, int dt, const ConvArgs& a, const ConvL& L
   Fp8Args q;
   q.w8 = folded ? L.w8_fold : L.w8_fwd;
   q.w_dequant = folded ? L.dq_fold : L.dq_fwd;
-  q.x_scale = 1.0f;       // post-BatchNorm activations sit in e4m3's normal range [2^-6, 448] as they are (include/sslcr.h)
+  // per-tensor activation scale by DELAYED scaling: this launch records the amax of what it quantises, the next forward of
+  // this net in this mode uses 2^floor(log2(448 / (2 amax))) (scale 1 until then); no host sync anywhere
+  q.x_scale = 1.0f;
+  q.x_scale_dev = L.f8s ? L.f8s + (folded ? 2 : 0) : nullptr;
+  q.amax_out = L.f8s ? L.f8s + (folded ? 3 : 1) : nullptr;
   if (!c->prof.on) return launch_conv_fp8(a, q, st);
   ProfRec r;
   r.e0 = c->prof.get(); r.e1 = c->prof.get();
@@ -426,6 +433,17 @@ int alloc_shadow(sslcr_net* n) {
       L.w8_fwd = (uint8_t*)q; L.w8_fold = (uint8_t*)(q + w8);
       L.dq_fwd = (float*)(q + 2 * w8); L.dq_fold = (float*)(q + 2 * w8 + bb);
     }
+  }
+  if (n->ctx->fp8) {
+    n->n8 = 0;
+    for (auto& pr : offs) if (pr.first->w8_fwd) n->n8 += 2;
+    TRYI(n->f8buf.ensure((size_t)n->n8 * 2 * sizeof(float)));
+    n->f8slots = (float*)n->f8buf.p;
+    std::vector<float> init((size_t)n->n8 * 2);
+    for (int i = 0; i < n->n8; ++i) { init[2 * i] = 1.f; init[2 * i + 1] = 0.f; }
+    TRY(hipMemcpy(n->f8slots, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
+    int k = 0;
+    for (auto& pr : offs) if (pr.first->w8_fwd) { pr.first->f8s = n->f8slots + 4 * k; ++k; }
   }
   return 0;
 }
@@ -1052,6 +1070,7 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
 
 int net_forward(sslcr_net* n, int train, const void* const* xs, int in_f32, int N, int H, int W, float* feats, float* logits, hipStream_t st) {
   if (!(train ? n->packed_train : n->packed_eval)) TRYI(sslcr_net_pack(n, train ? 1 : 2, st));   // shadow weights are stale
+  if (n->n8 > 0) TRY(launch_fp8_scale_update(n->f8slots, n->n8, st));      // fp8 delayed scaling: last forward's amax -> this one's scales
   if (train) n->packed_eval = false;               // running statistics are about to change
   const int npass = n->triplet ? 3 : 1;
   TRYI(alloc_heads(n, N));
@@ -1288,7 +1307,7 @@ int sslcr_net_create(sslcr_ctx* c, const sslcr_net_desc* d, sslcr_net** out) {
 int sslcr_net_destroy(sslcr_net* n) {
   if (!n) return 0;
   (void)hipDeviceSynchronize();
-  n->shadow.release(); n->grads.release(); n->heads.release(); n->descs.release();
+  n->shadow.release(); n->grads.release(); n->heads.release(); n->descs.release(); n->f8buf.release();
   for (int i = 0; i < 3; ++i) n->pass[i].mem.release();
   delete n;
   return 0;

@@ -52,6 +52,7 @@ int conv_fp8_rows(const ConvArgs& a);
 const char* conv_fp8_name(const ConvArgs& a);
 hipError_t launch_conv_fp8(const ConvArgs& a, const Fp8Args& q, hipStream_t st);
 hipError_t launch_pack_fp8(const PackFp8Args& a, hipStream_t st);
+hipError_t launch_fp8_scale_update(float* slots, int n, hipStream_t st);
 // conv_wgrad.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 int wgrad_halo_tw(const WgradArgs& a);

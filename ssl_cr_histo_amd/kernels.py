@@ -87,7 +87,7 @@ def pack_conv_fp8(w_kcrs, *, bn=None, eps=1e-5):
 
 
 def conv2d_fp8(x, w8, w_dequant, *, x_scale=1.0, in_scale=None, in_shift=None, in_relu=False, bias=None, residual=None, relu=False,
-               want_stats=False):
+               want_stats=False, amax_out=None):
     """fp8 (e4m3) forward conv 3x3 / stride 1 / pad 1: x bf16 NHWC [N,H,W,C], w8 [K,3,3,C] e4m3 bits -> y bf16 NHWC (+ stats)."""
     _chk(x, w8, w_dequant, in_scale, in_shift, bias, residual)
     assert x.dtype == torch.bfloat16 and w8.dtype == torch.uint8
@@ -96,7 +96,7 @@ def conv2d_fp8(x, w8, w_dequant, *, x_scale=1.0, in_scale=None, in_shift=None, i
     y = torch.empty((N, H, W, K), dtype=torch.bfloat16, device=x.device)
     d = L.ConvDesc(L.ptr(x), None, L.ptr(y), L.ptr(in_scale), L.ptr(in_shift), L.ptr(bias), L.ptr(residual), None,
                    N, H, W, C, K, 3, 3, 1, 1, H, W, H, W, 1, 0, int(in_relu), int(relu), 0, 0, 0, 0, 0)
-    q = L.Fp8Desc(L.ptr(w8), L.ptr(w_dequant), float(x_scale))
+    q = L.Fp8Desc(L.ptr(w8), L.ptr(w_dequant), float(x_scale), None, L.ptr(amax_out))
     stats = None
     if want_stats:
         rows = L.lib().sslcr_conv2d_fp8_partial_rows(d)

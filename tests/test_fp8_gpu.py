@@ -93,10 +93,12 @@ def test_conv_fp8_x_scale_and_saturation():
     w8, dq, _ = K.pack_conv_fp8(w.to(DEV))
     wq, dq_ref, _ = R.fp8_weight_pack(w)
     for xs in (1.0, 16.0, 0.25):
-        y = K.conv2d_fp8(x.to(DEV).to(torch.bfloat16), w8, dq, x_scale=xs)
+        amax = torch.zeros(1, device=DEV)
+        y = K.conv2d_fp8(x.to(DEV).to(torch.bfloat16), w8, dq, x_scale=xs, amax_out=amax)
         want, _ = R.conv3x3_fp8(x, wq, dq_ref, x_scale=xs)
         assert torch.isfinite(y.float()).all()
         close(y, want, 1.2e-2, f"x_scale {xs}")
+        assert abs(float(amax) - 1000.0) <= 4.0, float(amax)        # the amax the delayed scaling feeds on: before scale and clamp (bf16: 1000)
 
 
 def test_conv_fp8_rejects_unserved_shapes():
@@ -162,9 +164,13 @@ def test_fp8_config5_per_gpu_shape_vs_parity_engine():
         eng = E.Engine(DEV, dtype)
         mt, ct = build("finetune", "finetune", 2, True)
         ms, cs = build("finetune", "finetune", 2, True)
+        OMs = {k: v.clone() for k, v in ms.state_dict().items()}
         freeze(mt, 64)
         mt.eval(); ms.train()
         te, st = eng.bind(mt, ct), eng.bind(ms, cs)
+        if dtype == "fp8":         # delayed scaling: the first forward of a net runs at scale 1 and records amax; scales follow from the second on
+            eng.step_ssl_cr(te, st, "ce", x, y, u_w, u_s, 1.0, backward=False)
+            ms.load_state_dict(OMs)                    # undo the warm-up's running-statistics update: same starting state as the fp32 run
         r = eng.step_ssl_cr(te, st, "ce", x, y, u_w, u_s, 1.0)
         torch.cuda.synchronize()
         out[dtype] = dict(losses=r["losses"].cpu().double(), logits=r["logits"].cpu().double(), logits_t=r["logits_t"].cpu().double(),
