@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--aux-stream", type=int, default=0, choices=[0, 1],
                     help="1 = teacher forward on a second HIP stream next to the student forward (about -2 %% step time); off by "
                          "default because concurrent launches make the per-kernel durations of the roofline leg meaningless")
+    ap.add_argument("--wgrad-stream", type=int, default=0, choices=[0, 1],
+                    help="1 = backward's weight-gradient launches on a second HIP stream (measured neutral: 18.84 vs 18.76 ms/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the other configurations (forward-only, RSP, frozen, fp32 parity)")
@@ -213,7 +215,8 @@ def make_workload(name, eng, args, device, rank, world, modules_student=None):
         cfg = {"workload": f"eval_BreastPathQ_SSL_CR.train step, per-GPU --batch_size {b} --mu {mu}: student {nx}+{nu}, teacher {nu} "
                            f"({nx + 2 * nu} distinct {hw}x{hw} uint8 patches/step/GPU), modules_student={ms_freeze}, Adam",
                "global_batch_patches": (nx + 2 * nu) * world, "parallelism": f"dp{world}", "backward": ms_freeze < 60,
-               "bn_sync": bool(args.bn_sync) if world > 1 else None, "aux_stream": bool(args.aux_stream)}
+               "bn_sync": bool(args.bn_sync) if world > 1 else None, "aux_stream": bool(args.aux_stream),
+               "wgrad_stream": bool(args.wgrad_stream)}
         return step, nx + 2 * nu, flops, cfg, (mt, ct, ms, cs, opt)
     if name == "fwd":
         n = 4 * b
@@ -290,6 +293,7 @@ def main():
     sdist.attach_engine(eng)
     eng.set_bn_sync(bool(args.bn_sync))
     eng.set_aux_stream(bool(args.aux_stream))
+    eng.set_wgrad_stream(bool(args.wgrad_stream))
 
     def barrier():
         if world > 1:

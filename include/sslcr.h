@@ -285,6 +285,13 @@ int sslcr_set_bn_sync(sslcr_ctx* ctx, int on);
  * concurrent launches share the CUs, which makes per-kernel durations (HIP events and rocprofv3 alike) meaningless as a
  * statement about the kernel, and bench.py's roofline is built from those. */
 int sslcr_set_aux_stream(sslcr_ctx* ctx, int on);
+/* on: in backward the weight-gradient launches run on a second HIP stream behind an event -- they depend only on a
+ * BatchNorm-backward output and feed only the gradient buffer, and they are MFMA-bound while the chain they leave behind
+ * alternates MFMA-bound dgrads with HBM-bound BatchNorm passes.  Results are bit-identical.  OFF by default: measured
+ * neutral on MI355X (18.84 vs 18.76 ms/step) -- the 4096-workgroup elementwise kernels fill every wave slot of the CUs, so
+ * the 512-thread wgrad workgroups do not become co-resident and the two streams serialise.  Forced off while
+ * sslcr_profile() is on. */
+int sslcr_set_wgrad_stream(sslcr_ctx* ctx, int on);
 
 /* measurement: bracket every conv launch of this ctx with HIP events on its own stream (bench.py roofline leg).
  * which = 0: conv_igemm (forward + dgrad), 1: wgrad.  out4 = {launches, total ms, algorithmic FLOPs, algorithmic bytes}.

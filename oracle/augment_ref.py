@@ -38,3 +38,14 @@ def draw_params(n, src_hw, size, generator=None, p=0.5):
             left = int(torch.randint(0, sw - tw + 1, size=(1,), generator=generator).item())
         rows.append((flip, top, left))
     return torch.tensor(rows, dtype=torch.int32)
+
+
+def draw_fix_params(n, src_hw, size, generator=None, p=0.5):
+    """The torch-RNG draws of n successive ``TransformFix.__call__`` calls (dataset.py:672-677: ``self.weak(x)`` then
+    ``self.strong(x)``, whose RandAugment stage draws from Python's ``random`` / numpy, not torch): per sample
+    (flip, top, left) of the weak branch, then of the strong branch."""
+    weak, strong = [], []
+    for _ in range(n):
+        weak.append(draw_params(1, src_hw, size, generator, p)[0])
+        strong.append(draw_params(1, src_hw, size, generator, p)[0])
+    return torch.stack(weak), torch.stack(strong)

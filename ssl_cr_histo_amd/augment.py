@@ -55,3 +55,32 @@ class TransformFixWeak:
         n = batch_u8.shape[0]
         hw = (batch_u8.shape[1], batch_u8.shape[2]) if src_hwc else (batch_u8.shape[2], batch_u8.shape[3])
         return weak_augment(batch_u8, weak_params(n, hw, self.image_size, self.generator), self.image_size, src_hwc=src_hwc)
+
+
+def fix_params(n, src_hw, size, generator=None, p=0.5):
+    """The torch-RNG draws of n successive ``TransformFix.__call__`` (dataset.py:663-677): per sample the weak branch's
+    (flip, top, left) and then the strong branch's (flip, top, left) -- ``RandAugment`` draws from Python's ``random`` and numpy
+    (models/randaugment.py:53,133-135), so it does not move the torch stream.  -> (weak int32 [n,3], strong int32 [n,3])."""
+    weak = torch.empty((n, 3), dtype=torch.int32)
+    strong = torch.empty((n, 3), dtype=torch.int32)
+    for k in range(n):
+        weak[k] = weak_params(1, src_hw, size, generator, p)[0]
+        strong[k] = weak_params(1, src_hw, size, generator, p)[0]
+    return weak, strong
+
+
+class TransformFixGeometric:
+    """Batched, device-side counterpart of the DETERMINISTIC part of ``TransformFix(image_size, N)`` (row f4, first half): both
+    branches' ``RandomHorizontalFlip`` + ``RandomCrop`` with the reference's per-sample draw order, as two launches of the
+    gather kernel over the source batch in HBM.  -> (weak uint8 [N,3,S,S], strong_geometric uint8 [N,3,S,S]); the histology
+    ``RandAugment`` ops of the strong branch (models/randaugment.py:51-144) remain a host-side stage on the second output."""
+
+    def __init__(self, image_size, generator=None):
+        self.image_size, self.generator = image_size, generator
+
+    def __call__(self, batch_u8, src_hwc=False):
+        n = batch_u8.shape[0]
+        hw = (batch_u8.shape[1], batch_u8.shape[2]) if src_hwc else (batch_u8.shape[2], batch_u8.shape[3])
+        pw, ps = fix_params(n, hw, self.image_size, self.generator)
+        return (weak_augment(batch_u8, pw, self.image_size, src_hwc=src_hwc),
+                weak_augment(batch_u8, ps, self.image_size, src_hwc=src_hwc))

@@ -162,6 +162,16 @@ struct sslcr_ctx {
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_aux_begin = nullptr, ev_aux_end = nullptr;
   int use_aux = 0;                // sslcr_set_aux_stream
+  // weight-gradient side stream: in backward the wgrad launches (MFMA-bound, 3 ms of the step) depend only on a BatchNorm-backward
+  // output and feed nothing but the gradient buffer, while the chain they leave behind alternates MFMA-bound dgrads with
+  // HBM-bound BatchNorm passes (2.4 ms) that leave the matrix pipes idle -- so they are launched on a second stream behind an
+  // event and fill those gaps.  kinds: 0 = a block's conv2 (reads the dRaw2 scratch), 1 = conv1 (dRaw1), 2 = projection (dRawD);
+  // ev_wg_done[k] orders the NEXT writer of that scratch buffer behind the reader.
+  hipStream_t wg_stream = nullptr;
+  hipEvent_t ev_wg_in[3] = {nullptr, nullptr, nullptr}, ev_wg_done[3] = {nullptr, nullptr, nullptr}, ev_wg_join = nullptr;
+  bool wg_pending[3] = {false, false, false};
+  bool wg_any = false;            // something was launched on wg_stream since the last join
+  int use_wg = 0;                 // sslcr_set_wgrad_stream (default off: measured neutral, see include/sslcr.h; off while profiling)
   hipEvent_t ev_ready[8], ev_done = nullptr;
   DevBuf scratch;     // eval-forward activations and backward transients (never live at the same time)
   DevBuf partials;    // BN partial rows
@@ -874,17 +884,52 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
   return bn_bwd_end(c, a, st);
 }
 
+// the next writer of scratch buffer `kind` waits for the side-stream weight gradient that reads it
+int wg_wait(sslcr_ctx* c, int kind, hipStream_t st) {
+  if (c->wg_pending[kind]) {
+    TRY(hipStreamWaitEvent(st, c->ev_wg_done[kind], 0));
+    c->wg_pending[kind] = false;
+  }
+  return 0;
+}
+// `waiter` (the compute stream before the optimizer, the collective stream before a bucket) waits for every side-stream wgrad so far
+int wg_join(sslcr_ctx* c, hipStream_t waiter) {
+  if (!c->wg_any) return 0;
+  TRY(hipEventRecord(c->ev_wg_join, c->wg_stream));
+  TRY(hipStreamWaitEvent(waiter, c->ev_wg_join, 0));
+  return 0;
+}
+
 // seg_images > 0: the N images are N / seg_images segments (TripletNet branches) whose producer BatchNorms sit seg_stride floats apart
+// kind: which scratch buffer holds dy (0 conv2 / dRaw2, 1 conv1 / dRaw1, 2 projection / dRawD); < 0 = always on the compute stream
 int wgrad_call(sslcr_net* n, const ConvL& L, const void* x, const void* dy, const BnSaved* pro, int N, int H, int W, int OH, int OW, hipStream_t st,
-               int seg_images = 0, int seg_stride = 0) {
+               int seg_images = 0, int seg_stride = 0, int kind = -1) {
   if (!n->rg[L.pidx]) return 0;
+  sslcr_ctx* c = n->ctx;
   WgradArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.dy = dy; a.dw = (float*)n->grads.p + n->goff[L.pidx];
   if (pro) { a.in_scale = pro->scale; a.in_shift = pro->shift; a.in_relu = 1; }
   a.N = N; a.H = H; a.W = W; a.C = L.cin; a.K = L.cout; a.R = L.k; a.S = L.k; a.stride = L.stride; a.pad = L.pad; a.OH = OH; a.OW = OW;
   a.seg_images = seg_images; a.seg_stride = seg_stride;
-  TRY(prof_wgrad(n->ctx, n->ctx->dtype, a, st));
+  if (kind < 0 || !c->use_wg || c->prof.on) {
+    TRY(prof_wgrad(c, c->dtype, a, st));
+    return 0;
+  }
+  if (!c->wg_stream) {
+    TRY(hipStreamCreateWithFlags(&c->wg_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 3; ++k) {
+      TRY(hipEventCreateWithFlags(&c->ev_wg_in[k], hipEventDisableTiming));
+      TRY(hipEventCreateWithFlags(&c->ev_wg_done[k], hipEventDisableTiming));
+    }
+    TRY(hipEventCreateWithFlags(&c->ev_wg_join, hipEventDisableTiming));
+  }
+  TRY(hipEventRecord(c->ev_wg_in[kind], st));                  // dy (and, on the first launch, the zeroed gradient buffer) is ready
+  TRY(hipStreamWaitEvent(c->wg_stream, c->ev_wg_in[kind], 0));
+  TRY(prof_wgrad(c, c->dtype, a, c->wg_stream));
+  TRY(hipEventRecord(c->ev_wg_done[kind], c->wg_stream));
+  c->wg_pending[kind] = true;
+  c->wg_any = true;
   return 0;
 }
 
@@ -893,6 +938,7 @@ int launch_bucket_allreduce(sslcr_net* n, int bucket, size_t lo, size_t hi, hipS
   if (!sharded(c) || hi <= lo) return 0;
   TRY(hipEventRecord(c->ev_ready[bucket], st));
   TRY(hipStreamWaitEvent(c->comm_stream, c->ev_ready[bucket], 0));
+  TRYI(wg_join(c, c->comm_stream));                             // ... and the weight gradients of this bucket launched on the side stream
   float* g = (float*)n->grads.p + lo;
   TRYI(all_reduce(c, 1, g, hi - lo, false, c->comm_stream));
   return 0;
@@ -955,6 +1001,9 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
            *dRawD = buf(kRawD, p, so);
       // bn2 (+ relu mask from the block output): its REDUCE pass leaves G = dOut * (y > 0) in scratch; the apply pass, the
       // projection shortcut's BatchNorm and the identity path all read G instead of (dOut, y) again
+      // (the previous block's side-stream weight gradients may still be reading dRaw2 / dRawD: order these writers behind them)
+      TRYI(wg_wait(c, 0, st));
+      if (B.has_ds) TRYI(wg_wait(c, 2, st));
       // ... and with a projection shortcut the two reduce passes run back to back, so that sharded runs exchange both
       // BatchNorms' sums ([2][C] each, adjacent in bn_sums) in ONE all-reduce before the two apply passes
       if (B.has_ds) {
@@ -968,7 +1017,7 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       } else {
         TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, nullptr, 1));
       }
-      if (!c2_batched) TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st));
+      if (!c2_batched) TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st, 0, 0, 0));
       float* b1_rows = nullptr;
       int b1_nrows = 0;
       {
@@ -986,17 +1035,18 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
         }
         TRY(prof_conv(c, dt,a, st));
       }
+      TRYI(wg_wait(c, 1, st));
       TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, b1_rows ? 0 : 1, dRaw1, nullptr, opix, (double)opix, st,
                        nullptr, 0, b1_rows, b1_nrows));
     }
     // weight gradients: one launch over the npass * N images (x and dy contiguous across passes)
     if (c2_batched)
       TRYI(wgrad_call(n, B.c2, P[0].blk[i].raw1, buf(kRaw2, 0, so), &P[0].bn[B.b1.bidx], N * npass, oh, ow, oh, ow, st, N,
-                      (int)(P[1].bn[B.b1.bidx].scale - P[0].bn[B.b1.bidx].scale)));
+                      (int)(P[1].bn[B.b1.bidx].scale - P[0].bn[B.b1.bidx].scale), 0));
     {
       const char* X0 = i == 0 ? P[0].pooled : P[0].blk[i - 1].y;
-      TRYI(wgrad_call(n, B.c1, X0, buf(kRaw1, 0, so), nullptr, N * npass, xh, xw, oh, ow, st));
-      if (B.has_ds) TRYI(wgrad_call(n, B.ds, X0, buf(kRawD, 0, so), nullptr, N * npass, xh, xw, oh, ow, st));
+      TRYI(wgrad_call(n, B.c1, X0, buf(kRaw1, 0, so), nullptr, N * npass, xh, xw, oh, ow, st, 0, 0, 1));
+      if (B.has_ds) TRYI(wgrad_call(n, B.ds, X0, buf(kRawD, 0, so), nullptr, N * npass, xh, xw, oh, ow, st, 0, 0, 2));
     }
     if (need_dx) {
       {
@@ -1107,6 +1157,9 @@ int net_backward(sslcr_net* n, const float* dlogits, hipStream_t st) {
     TRY(hipEventRecord(c->ev_done, c->comm_stream));
     TRY(hipStreamWaitEvent(st, c->ev_done, 0));
   }
+  TRYI(wg_join(c, st));                       // the optimizer (and the next step's scratch writers) come after the side-stream wgrads
+  c->wg_any = false;
+  for (bool& pnd : c->wg_pending) pnd = false;
   return 0;
 }
 
@@ -1134,6 +1187,11 @@ int sslcr_create(sslcr_ctx** out, int device, int dtype) {
 int sslcr_destroy(sslcr_ctx* c) {
   if (!c) return 0;
   (void)hipDeviceSynchronize();
+  if (c->wg_stream) {
+    (void)hipStreamDestroy(c->wg_stream);
+    for (int k = 0; k < 3; ++k) { (void)hipEventDestroy(c->ev_wg_in[k]); (void)hipEventDestroy(c->ev_wg_done[k]); }
+    (void)hipEventDestroy(c->ev_wg_join);
+  }
   if (c->aux_stream) {
     (void)hipStreamDestroy(c->aux_stream);
     (void)hipEventDestroy(c->ev_aux_begin);
@@ -1212,6 +1270,12 @@ int sslcr_comm_unique_id(void* id256) {
 int sslcr_set_aux_stream(sslcr_ctx* c, int on) {
   if (!c) return fail("sslcr_set_aux_stream: null");
   c->use_aux = on ? 1 : 0;
+  return 0;
+}
+
+int sslcr_set_wgrad_stream(sslcr_ctx* c, int on) {
+  if (!c) return fail("sslcr_set_wgrad_stream: null");
+  c->use_wg = on ? 1 : 0;
   return 0;
 }
 

@@ -41,6 +41,7 @@ _ENGINE_SIGS = {
     "sslcr_comm_init_virtual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "sslcr_set_bn_sync": (C.c_int, [C.c_void_p, C.c_int]),
     "sslcr_set_aux_stream": (C.c_int, [C.c_void_p, C.c_int]),
+    "sslcr_set_wgrad_stream": (C.c_int, [C.c_void_p, C.c_int]),
     "sslcr_net_create": (C.c_int, [C.c_void_p, C.POINTER(SslcrNetDesc), C.POINTER(C.c_void_p)]),
     "sslcr_net_destroy": (C.c_int, [C.c_void_p]),
     "sslcr_net_set_requires_grad": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
@@ -284,6 +285,11 @@ class Engine:
         """True: step_ssl_cr runs the teacher forward on a second stream next to the student forward (-2 % step time; per-kernel
         timings then include the sharing of the CUs).  Default off."""
         L.check(L.lib().sslcr_set_aux_stream(self.handle, int(bool(on))))
+
+    def set_wgrad_stream(self, on):
+        """True: backward's weight-gradient launches run on a second stream (bit-identical results; measured neutral on MI355X,
+        off by default -- see include/sslcr.h)."""
+        L.check(L.lib().sslcr_set_wgrad_stream(self.handle, int(bool(on))))
 
     def _reduce_losses(self, losses):
         """logging only: each rank's (loss, loss_x, loss_u) is already scaled by 1/global-count and #correct is a count,

@@ -580,3 +580,21 @@ def test_weak_augment(shape, hwc):
     got = A.weak_augment(dev_src, prm, S, src_hwc=hwc)
     assert got.dtype == torch.uint8 and tuple(got.shape) == (N, 3, S, S)
     assert torch.equal(got.cpu(), want)
+
+
+def test_transform_fix_geometric_both_branches():
+    """row f4, deterministic half: both branches of TransformFix (dataset.py:663-677) -- flip + crop of the weak branch, then flip +
+    crop of the strong branch, drawn per sample in that order from ONE torch generator -- on the device, bit-exact against the
+    CPU restatement."""
+    from oracle import augment_ref as A
+    from ssl_cr_histo_amd import augment
+    n, sh, sw, size = 7, 300, 280, 256
+    src = torch.from_numpy(np.random.RandomState(77).randint(0, 256, (n, 3, sh, sw), dtype=np.uint8))
+    pw, ps = A.draw_fix_params(n, (sh, sw), size, torch.Generator().manual_seed(5))
+    weak, strong = augment.TransformFixGeometric(size, torch.Generator().manual_seed(5))(src.to(DEV))
+    assert torch.equal(weak.cpu(), A.weak_batch(src, pw, size))
+    assert torch.equal(strong.cpu(), A.weak_batch(src, ps, size))
+    assert not torch.equal(pw, ps)                           # the two branches really see different draws
+    g = torch.Generator().manual_seed(5)
+    mine = augment.fix_params(n, (sh, sw), size, g)
+    assert torch.equal(mine[0], pw) and torch.equal(mine[1], ps)
