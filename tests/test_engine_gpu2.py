@@ -436,3 +436,47 @@ def test_virtual_ranks_equal_the_single_device_step(world, workload, dtype):
     print(f"[{dtype}] {workload} world {world}: worst per-parameter gradient deviation from the single-device step {worst:.2e}")
     for e in engines:
         del e
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("workload", ["ssl_cr", "rsp"])
+def test_wgrad_side_stream_is_the_same_step(workload, dtype):
+    """sslcr_set_wgrad_stream: the weight-gradient launches of backward on a second stream (event-ordered behind their inputs, the
+    scratch buffers' next writers ordered behind them, joined before the optimizer) must give the gradients of the in-line step:
+    every parameter, three steps in a row on different batches with the parameters held fixed (the second and third steps
+    exercise the cross-step ordering of the scratch buffers; without an update in between, step k's gradients are comparable
+    to 1e-5 -- with updates a last-bit difference in the fp32 atomics' order flips ReLU masks on this tiny problem)."""
+    eng = _engine(dtype)
+    hw, nx, nu = 64, 8, 12
+    out = []
+    try:
+        for on in (False, True):
+            eng.set_wgrad_stream(on)
+            if workload == "rsp":
+                ms, cs = build("triplet", "mlp", 6, False)
+                xs = [C.u8(7201 + j, (nx, 3, hw, hw)) for j in range(3)]
+                y = C.ints(7210, (nx,), 6)
+            else:
+                mt, ct = build("finetune", "finetune", 1, True)
+                ms, cs = build("finetune", "finetune", 1, True)
+                freeze(mt, 64)
+                mt.eval()
+                te = eng.bind(mt, ct)
+                x, u_w, u_s = C.u8(7221, (nx, 3, hw, hw)), C.u8(7222, (nu, 3, hw, hw)), C.u8(7223, (nu, 3, hw, hw))
+                y = C.f32(7224, (nx,))
+            ms.train()
+            st = eng.bind(ms, cs)
+            grads = []
+            for k in range(3):
+                if workload == "rsp":
+                    eng.step_supervised(st, "ce", [torch.roll(v, k, 0) for v in xs], y, train=True)
+                else:
+                    eng.step_ssl_cr(te, st, "mse", torch.roll(x, k, 0), y, u_w, torch.roll(u_s, k, 0), 0.7)
+                grads.append([st.grad(i).cpu() for i in range(len(st.params))])
+            torch.cuda.synchronize()
+            out.append(grads)
+    finally:
+        eng.set_wgrad_stream(False)
+    for ga, gb in zip(out[0], out[1]):
+        for i, (a, b) in enumerate(zip(ga, gb)):
+            assert rel_err(b, a) < (1e-5 if dtype == "fp32" else 1e-3), i          # (fp32 atomics / slab folds in another order)
