@@ -201,6 +201,8 @@ typedef struct sslcr_loss_desc {
   float inv_nx_global, inv_nu_global;
 } sslcr_loss_desc;
 int sslcr_loss(const sslcr_loss_desc* d, void* stream);
+/* out[i] = softmax(logits[i, 0..C-1])[col]: the per-tile 'tumor' probability of test_Camelyon16.py:58-60 (row f3) */
+int sslcr_softmax_col(const float* logits, float* out, int n, int C, int col, void* stream);
 
 /* ---- optimizers (torch.optim.Adam / SGD nesterov as the reference configures them,
  *      eval_BreastPathQ_SSL_CR.py:481, eval_Camelyon_SSL_CR.py:514, pretrain_BreastPathQ.py:245; Lookahead lookahead.py:81-106) */

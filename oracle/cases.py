@@ -79,6 +79,8 @@ CASES = {
     # test_Camelyon16.test: forward-only WSI tile classification -> tumour-probability map ("next" row f3); the loader
     # yields (float32 RGB tile batch, x_mask, y_mask) for the tissue pixels of a mask, last batch ragged (:41-66)
     "cam_wsi": dict(script="cam_wsi", hw=64, b=4, classes=2, mask=(6, 5)),
+    # a slide-sized run of the same function: 26 x 19 mask (~220 tissue pixels) of 128x128 tiles in batches of 32, ragged tail
+    "cam_wsi_large": dict(script="cam_wsi", hw=128, b=32, classes=2, mask=(26, 19), head_scale=0.05),
 }
 
 PARAM_SEED = 42        # the reference's default --seed (eval_BreastPathQ_SSL_CR.py:253)

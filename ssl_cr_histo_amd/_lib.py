@@ -94,6 +94,7 @@ SIGNATURES = {
     "sslcr_linear_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "sslcr_linear_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "sslcr_loss": (i32, [P(LossDesc), vp]),
+    "sslcr_softmax_col": (i32, [vp, vp, i32, i32, i32, vp]),
     "sslcr_optimizer_step": (i32, [vp, i32, i32, P(OptDesc), vp]),
     "sslcr_axpby": (i32, [vp, vp, sz, f32, i32, vp]),
     "sslcr_fill": (i32, [vp, sz, f32, vp]),

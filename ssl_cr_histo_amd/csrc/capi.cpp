@@ -149,6 +149,11 @@ int sslcr_loss(const sslcr_loss_desc* d, void* stream) {
   return check(launch_loss(*d, (hipStream_t)stream), "loss");
 }
 
+int sslcr_softmax_col(const float* logits, float* out, int n, int C, int col, void* stream) {
+  NEED(logits && out && n > 0 && C > 0 && C <= 64 && col >= 0 && col < C, "args");
+  return check(launch_softmax_col(logits, out, n, C, col, (hipStream_t)stream), "softmax_col");
+}
+
 int sslcr_optimizer_step(const sslcr_tensor_desc* device_descs, int ntensors, int max_n, const sslcr_opt_desc* o, void* stream) {
   NEED(device_descs && o && ntensors > 0 && max_n > 0, "args");
   return check(launch_optimizer(device_descs, ntensors, max_n, *o, (hipStream_t)stream), "optimizer_step");

@@ -200,6 +200,8 @@ struct sslcr_net {
   DevBuf shadow, grads, heads, descs, chunks, f8buf;
   float* f8slots = nullptr;       // [n8][2] = {x_scale, amax since the last update}: two slots (train, eval) per fp8 conv, see ConvL::f8s
   int n8 = 0;
+  bool f8_cal[2] = {false, false};  // the first forward of this net in (train, eval) mode has calibrated the activation scales
+  bool f8_calib_pass = false;       // a calibration pass is running: no running-statistics update, outputs discarded
   int nchunks = 0;
   bool opt_packs_all = false;     // the optimizer work list rewrites every non-stem conv's train-mode shadow weights
   size_t grad_count = 0;
@@ -506,6 +508,7 @@ int finalize_bn(sslcr_net* n, const BnL& bn, const float* partials, int rows, do
   a.gamma = n->params[bn.pg]; a.beta = n->params[bn.pb];
   a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
   a.running_mean = n->bn_rm[bn.bidx]; a.running_var = n->bn_rv[bn.bidx]; a.num_batches_tracked = n->bn_nbt[bn.bidx];
+  if (n->f8_calib_pass) { a.running_mean = nullptr; a.running_var = nullptr; a.num_batches_tracked = nullptr; }
   a.momentum = 0.1f; a.eps = 1e-5f; a.replay = replay;
   a.stage = c->bn_stage;
   if (sharded(c) && c->bn_sync) {
@@ -1120,6 +1123,21 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
 
 int net_forward(sslcr_net* n, int train, const void* const* xs, int in_f32, int N, int H, int W, float* feats, float* logits, hipStream_t st) {
   if (!(train ? n->packed_train : n->packed_eval)) TRYI(sslcr_net_pack(n, train ? 1 : 2, st));   // shadow weights are stale
+  const int npass_ = n->triplet ? 3 : 1;
+  if (n->n8 > 0 && !n->f8_cal[train ? 0 : 1]) {
+    // fp8 delayed scaling needs one forward to have seen the data: the FIRST forward of a net in a mode runs twice -- a
+    // calibration pass at scale 1 (amax recorded, BatchNorm running statistics untouched, outputs overwritten below), then the
+    // real one with the scales it produced
+    n->f8_cal[train ? 0 : 1] = true;
+    n->f8_calib_pass = true;
+    TRYI(alloc_heads(n, N));
+    int rc = 0;
+    for (int i = 0; i < npass_ && rc == 0; ++i)
+      rc = train ? backbone_forward_train(n, n->pass[i], xs[i], in_f32, N, H, W, n->triplet ? 1 : 3, st)
+                 : backbone_forward_eval(n, xs[i], in_f32, N, H, W, n->dE[i], st);
+    n->f8_calib_pass = false;
+    if (rc) return rc;
+  }
   if (n->n8 > 0) TRY(launch_fp8_scale_update(n->f8slots, n->n8, st));      // fp8 delayed scaling: last forward's amax -> this one's scales
   if (train) n->packed_eval = false;               // running statistics are about to change
   const int npass = n->triplet ? 3 : 1;

@@ -209,6 +209,22 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossArgs a) {
   }
 }
 
+// out[i] = softmax(logits[i, :])[col] -- the 'tumor' probability of test_Camelyon16.py:58-60
+__global__ __launch_bounds__(256) void softmax_col_kernel(const float* logits, float* out, int n, int C, int col) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* l = logits + (long)i * C;
+  float m = l[0];
+  for (int c = 1; c < C; ++c) m = fmaxf(m, l[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += expf(l[c] - m);
+  out[i] = expf(l[col] - m) / s;
+}
+hipError_t launch_softmax_col(const float* logits, float* out, int n, int C, int col, hipStream_t st) {
+  hipLaunchKernelGGL(softmax_col_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, logits, out, n, C, col);
+  return hipGetLastError();
+}
+
 hipError_t launch_loss(const LossArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(256), 0, st, a);
   return hipGetLastError();

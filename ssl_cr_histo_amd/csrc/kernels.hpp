@@ -81,6 +81,7 @@ hipError_t launch_linear_fwd(const float* x, const float* w, const float* b, flo
 hipError_t launch_linear_bwd(const float* x, const float* w, const float* dy, const float* yact, float* dx, float* dw, float* db,
                              int M, int N, int K, int dx_accumulate, float* scratch, hipStream_t st);
 hipError_t launch_loss(const LossArgs& a, hipStream_t st);
+hipError_t launch_softmax_col(const float* logits, float* out, int n, int C, int col, hipStream_t st);
 // augment.hip
 hipError_t launch_weak_augment(const sslcr_weak_aug_desc& a, hipStream_t st);
 // optim.hip

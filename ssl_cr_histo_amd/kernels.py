@@ -308,3 +308,12 @@ def loss(kind, logits, *, logits_t=None, target_f=None, target_i=None, nx, lambd
                    Cn, lambda_u, 1.0 / (nx_global or nx), 1.0 / max(1, (nu_global or nu)))
     L.check(L.lib().sslcr_loss(d, L.stream_ptr()))
     return out, dl
+
+
+def softmax_col(logits, col=-1):
+    """softmax(logits, dim=1)[:, col] for fp32 logits [N, C] (test_Camelyon16.py:58-60)."""
+    _chk(logits)
+    n, c = logits.shape
+    out = torch.empty(n, dtype=torch.float32, device=logits.device)
+    L.check(L.lib().sslcr_softmax_col(L.ptr(logits), L.ptr(out), n, c, col % c, L.stream_ptr()))
+    return out

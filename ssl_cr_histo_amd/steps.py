@@ -331,6 +331,7 @@ def camelyon16_test(args, model, classifier, test_loader):
     """test_Camelyon16.test (test_Camelyon16.py:30-70) -> probs_map: every tissue pixel of ``test_loader.dataset.mask``
     gets the softmax 'tumor' probability of its tile; forward-only (BatchNorm folded, all epilogues fused)."""
     import numpy as np
+    from . import kernels as K
     eng = get_engine(_device_of(model))
     model.eval()
     classifier.eval()
@@ -339,7 +340,7 @@ def camelyon16_test(args, model, classifier, test_loader):
     t0 = time.time()
     for batch_idx, (input, x_mask, y_mask) in enumerate(test_loader):
         _, output = net.forward((input,), train=False)
-        probs = torch.softmax(output, dim=1)[:, -1].cpu().numpy()           # second column 'tumor' (:58-60)
+        probs = K.softmax_col(output.contiguous(), -1).cpu().numpy()        # second column 'tumor' (:58-60)
         probs_map[x_mask.numpy(), y_mask.numpy()] = probs
         if (batch_idx + 1) % 10 == 0 and getattr(args, "print_freq", 0):
             print("Test: [{0}/{1}]\tBT {2:.3f}".format(batch_idx, _len(test_loader), (time.time() - t0) / (batch_idx + 1)))

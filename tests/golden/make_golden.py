@@ -391,7 +391,12 @@ def gen_cam_wsi(name, out):
     """test_Camelyon16.test(): forward-only tile classification -> probability map ("next" row f3)."""
     m = importlib.import_module("test_Camelyon16")
     model, cls = build("finetune", "finetune", 2, rand_stats=True)
-    loader = C.wsi_loader(name)
+    if name != "cam_wsi":
+        # the seeded random head saturates the softmax (every 'tumor' probability < 1e-6): shrink it so that the map spreads over (0, 1)
+        with torch.no_grad():
+            cls.classifier[0].weight.mul_(C.CASES[name]["head_scale"])
+            cls.classifier[0].bias.mul_(C.CASES[name]["head_scale"])
+    loader = C.wsi_loader(name, 6000 if name == "cam_wsi" else 6500)
     pm = m.test(args_ns(), model, cls, loader)
     out[f"{name}/ret"] = np.asarray(pm, dtype=np.float64)
     out[f"{name}/mask"] = loader.dataset.mask
@@ -794,7 +799,7 @@ def gen_stages(out):
 def main():
     gens = {"bpq_cr_f60": gen_bpq_cr, "bpq_cr_f0": gen_bpq_cr, "cam_cr_f60": gen_cam_cr, "cam_cr_f0": gen_cam_cr,
             "kather_cr_f0": gen_kather_cr, "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup,
-            "cam_wsi": gen_cam_wsi, "bpq_cr_full": gen_bpq_cr_full, "rsp_full": gen_rsp_full, "cam_cr_full": gen_cam_cr_full,
+            "cam_wsi": gen_cam_wsi, "cam_wsi_large": gen_cam_wsi, "bpq_cr_full": gen_bpq_cr_full, "rsp_full": gen_rsp_full, "cam_cr_full": gen_cam_cr_full,
             "kather_sup": gen_kather_sup, "kather_sup_full": gen_kather_sup_full, "traj_bpq_cr": gen_traj, "traj_cam_cr": gen_traj,
             "ckpt_bpq_cr": gen_ckpt_bpq_cr, "ckpt_cam_sup": gen_ckpt_cam_sup, "ckpt_rsp": gen_ckpt_rsp}
     only = sys.argv[1:]

@@ -480,3 +480,27 @@ def test_wgrad_side_stream_is_the_same_step(workload, dtype):
     for ga, gb in zip(out[0], out[1]):
         for i, (a, b) in enumerate(zip(ga, gb)):
             assert rel_err(b, a) < (1e-5 if dtype == "fp32" else 1e-3), i          # (fp32 atomics / slab folds in another order)
+
+
+# ------------------------------------------------------------------------------------------------ f3: slide-sized WSI map
+@pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp8"])
+def test_cam_wsi_slide_sized_map_vs_reference(dtype):
+    """test_Camelyon16.test() (test_Camelyon16.py:30-70) on a 26 x 19 tissue mask: 220 tiles of 128x128 in batches of 32 with a ragged
+    tail, eval forward + the softmax 'tumor' column (a HIP kernel, sslcr_softmax_col) scattered into the mask-shaped map, against the
+    map the reference's own test() produced (probabilities spread over 0.23..0.33)."""
+    from ssl_cr_histo_amd.scripts import test_Camelyon16 as script
+    _engine(dtype)
+    name = "cam_wsi_large"
+    g = load_golden(name)
+    model, cls = build("finetune", "finetune", 2, True)
+    with torch.no_grad():
+        cls.classifier[0].weight.mul_(C.CASES[name]["head_scale"])
+        cls.classifier[0].bias.mul_(C.CASES[name]["head_scale"])
+    loader = C.wsi_loader(name, 6500)
+    pm = script.test(ns(), model, cls, loader)
+    want = g[f"{name}/ret"]
+    assert pm.shape == want.shape and pm.dtype == np.float64
+    assert np.array_equal(pm == 0, ~g[f"{name}/mask"])
+    err = float(np.abs(pm - want).max())
+    print(f"[{dtype}] slide-sized probability map: max abs error {err:.2e} (values 0.23..0.33)")
+    assert err <= {"fp32": 1e-4, "bf16": 2e-2, "fp8": 3e-2}[dtype], err

@@ -148,6 +148,21 @@ def test_cam_wsi_probability_map():
         assert np.abs(pm - g[f"{name}/ret"]).max() <= 1e-5
 
 
+def test_cam_wsi_slide_sized_map():
+    """the same function on a 26 x 19 mask (220 tissue tiles of 128x128, batches of 32, ragged tail) with a head scaled so that the
+    probabilities spread over (0.23, 0.33) instead of saturating."""
+    name = "cam_wsi_large"
+    g = load_golden(name)
+    pn, bn, pc = oracle_state("finetune", 2, True)
+    for k in pc:
+        pc[k] = pc[k] * C.CASES[name]["head_scale"]
+    loader = C.wsi_loader(name, 6500)
+    assert np.array_equal(loader.dataset.mask, g[f"{name}/mask"]) and int(loader.dataset.mask.sum()) == 220
+    pm = E.cam_wsi_test(merged(pn, pc), bn, loader, False)
+    assert np.array_equal(pm == 0, ~g[f"{name}/mask"])
+    assert np.abs(pm - g[f"{name}/ret"]).max() <= 1e-5
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_stage_activations(mode):
     g = load_golden("stages")
