@@ -358,7 +358,7 @@ def _run_ranks(world, fn):
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("workload", ["ssl_cr_ce", "ssl_cr_mse", "rsp"])
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_virtual_ranks_equal_the_single_device_step(world, workload, dtype):
     """The engine's SHARDED code path against its own 1-rank step on the concatenated batch: `world` contexts on this one GPU,
     each with 1/world of the batch, exchanging through the virtual communicator (include/sslcr.h: sslcr_vcomm -- same call sites
@@ -371,6 +371,8 @@ def test_virtual_ranks_equal_the_single_device_step(world, workload, dtype):
     worth tens of percent on the backbone gradients (oracle/bf16_emul.py; tools/bf16_sources.py; measured here: a flat 16 % from
     conv1 to fc.0 with losses equal to 5e-4) -- so bf16 is only held to 0.6 on the gradients, 1e-2 on the losses and 0.1 on the post-step state (lr 1e-2 SGD of those gradients); the arithmetic is pinned by the fp32 rows."""
     from ssl_cr_histo_amd import engine as E
+    if world == 8 and (workload != "ssl_cr_mse" or dtype != "fp32"):
+        pytest.skip("world 8 (the node size of BASELINE configs 4 and 5) is covered once, on the headline workload in the parity mode")
     hw = 64
     rsp = workload == "rsp"
     kind = "mse" if workload == "ssl_cr_mse" else "ce"

@@ -107,3 +107,39 @@ def test_weak_augment_params_follow_the_reference_draw_order():
         assert torch.equal(torch.rand(3, generator=g1), torch.rand(3, generator=g2))
     with pytest.raises(ValueError):
         A.weak_params(1, (32, 32), 64)
+
+
+def test_bench_spawns_ranks_itself_and_refuses_more_gpus_than_visible(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself through torch.distributed.run (the driver's form for N = 1
+    is the bare script); on a box with fewer GPUs it must stop with a clear message, not hang in a rendezvous."""
+    import importlib
+    import subprocess
+    import sys
+    import pytest
+    import types
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    args = types.SimpleNamespace(gpus=8)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(args)
+    assert "only 1 GPU(s) visible" in str(e.value)
+    # with enough GPUs: one torch.distributed.run child with --nproc-per-node N, loopback rendezvous, the original arguments
+    seen = {}
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3"])
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=0)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    with pytest.raises(SystemExit) as e:
+        bench.spawn_ranks(args)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
