@@ -185,6 +185,12 @@ typedef struct sslcr_bn_bwd_desc {
 int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, void* stream);
+/* conv1 wgrad with bn0's backward apply pass computed on the fly (autograd of resnet18.conv1 <- bn1 <- relu <- maxpool,
+ * models/net.py:32,77): `bn` is a pool-form descriptor (pool_dy, pool_argmax, x = the raw conv1 output, pH/pW = w->OH/OW) whose
+ * reduce pass has run (sums final, all-reduced when sharded); the un-pooled gradient (bn->dx, w->dy) is never written or read --
+ * each workgroup derives its 8x16 dY tile in LDS.  dgamma/dbeta are accumulated as sslcr_bn_bwd_apply would.  Same result, bit for
+ * bit, as sslcr_bn_bwd_apply followed by sslcr_stem_wgrad. */
+int sslcr_stem_wgrad_pool(int dtype, const sslcr_stem_wgrad_desc* w, const sslcr_bn_bwd_desc* bn, void* stream);
 
 /* ---- heads and losses (models/net.py:12-15,35-36,111; F.mse_loss / F.cross_entropy at
  *      eval_BreastPathQ_SSL_CR.py:92-95, eval_Camelyon_SSL_CR.py:110-116, pretrain_BreastPathQ.py:56) */

@@ -82,6 +82,7 @@ SIGNATURES = {
     "sslcr_stem_conv": (i32, [i32, P(StemDesc), vp]),
     "sslcr_stem_partial_rows": (i32, [P(StemDesc)]),
     "sslcr_stem_wgrad": (i32, [i32, P(StemWgradDesc), vp]),
+    "sslcr_stem_wgrad_pool": (i32, [i32, P(StemWgradDesc), P(BnBwdDesc), vp]),
     "sslcr_bn_finalize": (i32, [P(BnFinalizeDesc), vp]),
     "sslcr_bn_act": (i32, [i32, P(BnActDesc), vp]),
     "sslcr_bn_relu_maxpool": (i32, [i32, P(PoolFwdDesc), vp]),

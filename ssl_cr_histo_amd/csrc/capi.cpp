@@ -85,6 +85,14 @@ int sslcr_stem_wgrad(int dtype, const sslcr_stem_wgrad_desc* d, void* stream) {
   NEED(!d->x2 || (d->n_split >= 0 && d->n_split <= d->N), "n_split outside the batch");
   return check(launch_stem_wgrad(dtype, *d, (hipStream_t)stream), "stem_wgrad");
 }
+int sslcr_stem_wgrad_pool(int dtype, const sslcr_stem_wgrad_desc* w, const sslcr_bn_bwd_desc* bn, void* stream) {
+  DT_OK(dtype);
+  NEED(w && w->x && w->dw && bn && bn->pool_dy && bn->pool_argmax && bn->x && bn->sums && bn->mean && bn->invstd && bn->scale && bn->shift, "null tensor");
+  NEED(!w->x2 || (w->n_split >= 0 && w->n_split <= w->N), "n_split outside the batch");
+  NEED(bn->C == 64 && bn->pH == w->OH && bn->pW == w->OW && bn->pixels == (size_t)w->N * w->OH * w->OW, "bn descriptor is not this stem's");
+  NEED(!bn->g_in_reduce && !bn->gout, "pool form has no g output");
+  return check(launch_stem_wgrad_pool(dtype, *w, *bn, (hipStream_t)stream), "stem_wgrad_pool");
+}
 
 int sslcr_bn_finalize(const sslcr_bn_finalize_desc* d, void* stream) {
   NEED(d && d->C > 0, "desc");

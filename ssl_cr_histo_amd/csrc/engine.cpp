@@ -171,6 +171,7 @@ struct sslcr_ctx {
   hipEvent_t ev_wg_in[3] = {nullptr, nullptr, nullptr}, ev_wg_done[3] = {nullptr, nullptr, nullptr}, ev_wg_join = nullptr;
   bool wg_pending[3] = {false, false, false};
   bool wg_any = false;            // something was launched on wg_stream since the last join
+  int fuse_stem_bwd = 1;          // conv1 wgrad derives dY from the pooled gradient in LDS (SSLCR_FUSE_STEM_BWD=0: apply pass + wgrad, for A/B runs)
   int use_wg = 0;                 // sslcr_set_wgrad_stream (default off: measured neutral, see include/sslcr.h; off while profiling)
   hipEvent_t ev_ready[8], ev_done = nullptr;
   DevBuf scratch;     // eval-forward activations and backward transients (never live at the same time)
@@ -1107,14 +1108,36 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       PassState& ps = P[p];
       PoolSrc pool{buf(kOut, p, (size_t)N * d.ph * d.pw * 64 * es), ps.argmax, d.oh0, d.ow0, d.ph, d.pw, ps.pooled};
       const size_t spix = (size_t)N * d.oh0 * d.ow0;
-      TRYI(bn_backward(n, n->bn0, ps.bn[0], nullptr, ps.raw0, nullptr, 1, dRaw0, nullptr, spix, (double)spix, st, &pool));
-      if (n->rg[0]) {
-        StemWgradArgs w;
-        memset(&w, 0, sizeof(w));
-        w.x = ps.x; w.x2 = ps.x2; w.n_split = ps.n_split; w.dy = dRaw0; w.dw = (float*)n->grads.p + n->goff[0];
-        w.N = N; w.H = ps.H; w.W = ps.W; w.OH = d.oh0; w.OW = d.ow0; w.in_f32 = ps.in_f32;
-        TRY(launch_stem_wgrad(dt, w, st));
+      StemWgradArgs w;
+      memset(&w, 0, sizeof(w));
+      w.x = ps.x; w.x2 = ps.x2; w.n_split = ps.n_split; w.dy = dRaw0; w.dw = (float*)n->grads.p + n->goff[0];
+      w.N = N; w.H = ps.H; w.W = ps.W; w.OH = d.oh0; w.OW = d.ow0; w.in_f32 = ps.in_f32;
+      if (n->rg[0] && c->fuse_stem_bwd) {
+        // conv1 wgrad derives its dY tiles from the pooled gradient itself: the apply pass and its 2 x (N x 128 x 128 x 64)
+        // round trip through HBM are gone (sslcr_stem_wgrad_pool)
+        BnBwdArgs a;
+        TRYI(bn_bwd_begin(n, n->bn0, ps.bn[0], nullptr, ps.raw0, nullptr, 1, nullptr, nullptr, spix, (double)spix, st, c->bn_sums, &a, &pool));
+        TRYI(bn_bwd_sync(c, c->bn_sums, 2 * 64, st));
+        w.dy = nullptr;
+        if (c->prof.on) {
+          ProfRec r;
+          r.e0 = c->prof.get(); r.e1 = c->prof.get();
+          r.name = dt == DT_BF16 ? "sslcr::stem_wgrad_kernel<unsigned short, pool>" : "sslcr::stem_wgrad_kernel<float, pool>";
+          r.flops = 0.0;        // listed with the HBM-bound kernels (0.1 flop per byte)
+          const double t = (double)spix * 64 * c->esz();
+          r.bytes = 0.25 * t + 0.25 * (double)spix * 64 + t + (double)N * 3 * ps.H * ps.W * (ps.in_f32 ? 4 : 1);
+          (void)hipEventRecord(r.e0, st);
+          hipError_t e = launch_stem_wgrad_pool(dt, w, a, st);
+          (void)hipEventRecord(r.e1, st);
+          c->prof.rec[2].push_back(r);
+          TRY(e);
+        } else {
+          TRY(launch_stem_wgrad_pool(dt, w, a, st));
+        }
+        continue;
       }
+      TRYI(bn_backward(n, n->bn0, ps.bn[0], nullptr, ps.raw0, nullptr, 1, dRaw0, nullptr, spix, (double)spix, st, &pool));
+      if (n->rg[0]) TRY(launch_stem_wgrad(dt, w, st));
     }
   }
   TRYI(launch_bucket_allreduce(n, bucket, 0, hi_pending, st));
@@ -1190,6 +1213,7 @@ int sslcr_create(sslcr_ctx** out, int device, int dtype) {
   TRY(hipSetDevice(device));
   sslcr_ctx* c = new sslcr_ctx();
   c->device = device; c->dtype = dtype == SSLCR_FP8 ? SSLCR_BF16 : dtype; c->fp8 = dtype == SSLCR_FP8;
+  if (const char* e = getenv("SSLCR_FUSE_STEM_BWD")) c->fuse_stem_bwd = atoi(e) != 0;
   if (c->small.ensure(32 * 2 * 512 * sizeof(double) + 2 * 2 * 512 * sizeof(double) + 2 * 512 * sizeof(float)) != 0) { delete c; return -1; }
   c->bn_stage = (double*)c->small.p;
   c->bn_sums = c->bn_stage + 32 * 2 * 512;        // two [2][C] slots (bn2 + projection BatchNorm of a block share an all-reduce)

@@ -331,8 +331,15 @@ hipError_t launch_stem(int dtype, const StemArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------ stem wgrad
 // D[kout][feature (r,s8,c4)] = sum_pixels dY^T[kout][pixel] * patch[pixel][feature]; the patch operand is read straight
 // out of the halo with per-lane addresses (ds_read_b64_tr_b16 delivers the pixel-major -> K-major transpose for free).
-template <typename T, bool INF32>
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, int tiles_h, int tiles_w, int ntiles, f32x4_t* partials) {
+//
+// POOL form (sslcr_stem_wgrad_pool): dY is never in memory.  The stem's gradient arrives through maxpool3x3/2 -> ReLU -> bn0, and
+// the BatchNorm-backward apply pass (bn_bwd_apply_pool_kernel: pooled gradient + argmax codes + raw conv output -> dY) is run on
+// the tile while it is staged: thread = (2x2 pixel block, 16-byte channel chunk) of the 8x16 tile, exactly the work item of that
+// kernel, writing its four dY chunks into the LDS tile instead of 2.3 GB of HBM that this kernel would read straight back.
+struct StemPoolRaw { u32x4_t dv[4]; uint32_t am[4][2]; u32x4_t xv[4]; };
+
+template <typename T, bool INF32, bool POOL>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, const BnBwdArgs b, int tiles_h, int tiles_w, int ntiles, f32x4_t* partials) {
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int PS = BF ? 32 : 16;               // pixels per MFMA depth step
@@ -353,7 +360,27 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
 #pragma unroll
   for (int f = 0; f < 14; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  u32x4_t yreg[YL];
+  constexpr int IT = POOL ? (TH / 2) * (TW / 2) * CPR / 256 : 1;     // POOL work items per thread and tile (1 / 2)
+  u32x4_t yreg[POOL ? 1 : YL];
+  StemPoolRaw praw[IT];
+  float cA[EPC], cB[EPC], cC[EPC], rsh[EPC];     // POOL: dY = cA g + cB x + cC for this thread's channel chunk (bn_bwd_apply_pool_kernel)
+  if constexpr (POOL) {
+    const float invM = (float)(1.0 / b.count);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = chunk * EPC + e;
+      const float is = b.invstd[c], sc = b.scale[c];
+      const float m0 = (float)b.sums[c] * invM, m1 = (float)b.sums[64 + c] * invM;
+      cA[e] = sc;
+      cB[e] = -sc * is * is * m1;
+      cC[e] = -sc * m0 - cB[e] * b.mean[c];
+      rsh[e] = b.shift[c];
+    }
+    if (blockIdx.x == 0 && b.dgamma && b.dbeta && tid < 64) {        // affine gradients, as workgroup 0 of the apply pass does
+      b.dgamma[tid] += (float)(b.sums[64 + tid] * (double)b.invstd[tid] * (double)b.pg_scale);
+      b.dbeta[tid] += (float)(b.sums[tid] * (double)b.pg_scale);
+    }
+  }
   StemRaw raw{{0u, 0u, 0u}};
   auto issue = [&](int tile) {
     const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
@@ -363,14 +390,41 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
       const void* xseg = stem_seg(a, ns);
       raw = stem_issue4(xseg, ns, a.H, a.W, 2 * ho0 - 3, 2 * wo0 - 3);
     }
+    if constexpr (POOL) {
+      const char* xg = reinterpret_cast<const char*>(b.x);
+      const char* dyg = reinterpret_cast<const char*>(b.pool_dy);
 #pragma unroll
-    for (int i = 0; i < YL; ++i) {
-      const int p = row + (256 / CPR) * i;
-      const int ho = ho0 + p / TW, wo = wo0 + p % TW;
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (ho < a.OH && wo < a.OW)
-        v = ld16(reinterpret_cast<const char*>(a.dy) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64 + chunk * EPC) * sizeof(T));
-      yreg[i] = v;
+      for (int it = 0; it < IT; ++it) {
+        const int blk = (tid + 256 * it) / CPR;
+        const int bh = (ho0 >> 1) + blk / (TW / 2), bw = (wo0 >> 1) + blk % (TW / 2);
+        // the four windows and the four pixels: unconditional loads from clamped addresses, validity applied in commit
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int oh = bh + (q >> 1), ow = bw + (q & 1);
+          const int ohc = oh < b.pOH ? oh : b.pOH - 1, owc = ow < b.pOW ? ow : b.pOW - 1;
+          const size_t o = (((size_t)n * b.pOH + ohc) * b.pOW + owc) * CPR + chunk;
+          praw[it].dv[q] = ld16_nt(dyg + o * 16);
+          if constexpr (EPC == 8) {
+            const u32x2_t v = *reinterpret_cast<const u32x2_t*>(b.pool_argmax + o * EPC);
+            praw[it].am[q][0] = v[0]; praw[it].am[q][1] = v[1];
+          } else {
+            praw[it].am[q][0] = *reinterpret_cast<const uint32_t*>(b.pool_argmax + o * EPC); praw[it].am[q][1] = 0;
+          }
+          const int h = 2 * bh + (q >> 1), w = 2 * bw + (q & 1);
+          const int hc = h < a.OH ? h : a.OH - 1, wc = w < a.OW ? w : a.OW - 1;
+          praw[it].xv[q] = ld16_nt(xg + ((((size_t)n * a.OH + hc) * a.OW + wc) * CPR + chunk) * 16);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < YL; ++i) {
+        const int p = row + (256 / CPR) * i;
+        const int ho = ho0 + p / TW, wo = wo0 + p % TW;
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (ho < a.OH && wo < a.OW)
+          v = ld16(reinterpret_cast<const char*>(a.dy) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64 + chunk * EPC) * sizeof(T));
+        yreg[i] = v;
+      }
     }
   };
   auto commit = [&](int tile, int buf) {
@@ -384,8 +438,57 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
       const void* xseg = stem_seg(a, n);
       stem_load_halo<T, INF32>(hl, xseg, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3);
     }
+    if constexpr (POOL) {
+      const int rem = tile % (tiles_h * tiles_w);
+      const int ho0 = (rem / tiles_w) * TH, wo0 = (rem % tiles_w) * TW;
 #pragma unroll
-    for (int i = 0; i < YL; ++i) st16(yt + (row + (256 / CPR) * i) * RB + chunk * 16, yreg[i]);
+      for (int it = 0; it < IT; ++it) {
+        const int blk = (tid + 256 * it) / CPR;
+        const int lh = 2 * (blk / (TW / 2)), lw = 2 * (blk % (TW / 2));
+        // branch-free throughout: a window outside the pooled map contributes zeros, the argmax match is a select
+        float dw[4][EPC];
+        uint32_t cd[4][EPC];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool wok = ((ho0 + lh) >> 1) + (q >> 1) < b.pOH && ((wo0 + lw) >> 1) + (q & 1) < b.pOW;
+          u32x4_t v = praw[it].dv[q];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = wok ? v[j] : 0u;
+          Elem<T>::unpack(v, dw[q]);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) cd[q][e] = (praw[it].am[q][e >> 2] >> (8 * (e & 3))) & 0xffu;
+        }
+        const float thr = b.relu_from_x ? 0.f : -__builtin_inff();   // ReLU between the BatchNorm and the pool: g lives where y > thr
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+          for (int pj = 0; pj < 2; ++pj) {
+            float xf[EPC], g[EPC], d[EPC];
+            Elem<T>::unpack(praw[it].xv[pi * 2 + pj], xf);
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) g[e] = 0.f;
+#pragma unroll
+            for (int di = 0; di <= pi; ++di)
+#pragma unroll
+              for (int dj = 0; dj <= pj; ++dj) {
+                const uint32_t code = (uint32_t)((pi - 2 * di + 1) * 3 + (pj - 2 * dj + 1));
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) g[e] += cd[di * 2 + dj][e] == code ? dw[di * 2 + dj][e] : 0.f;
+              }
+            const bool pok = ho0 + lh + pi < a.OH && wo0 + lw + pj < a.OW;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+              const float ge = fmaf(xf[e], cA[e], rsh[e]) > thr ? g[e] : 0.f;
+              const float de = fmaf(cA[e], ge, fmaf(cB[e], xf[e], cC[e]));
+              d[e] = pok ? de : 0.f;
+            }
+            st16(yt + ((lh + pi) * TW + lw + pj) * RB + chunk * 16, Elem<T>::pack(d));
+          }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < YL; ++i) st16(yt + (row + (256 / CPR) * i) * RB + chunk * 16, yreg[i]);
+    }
   };
 
   __syncthreads();                               // zero fill (4th halo channel stays 0 on the slow path)
@@ -481,13 +584,12 @@ __global__ __launch_bounds__(256) void stem_wgrad_fold_kernel(const f32x4_t* __r
   }
 }
 
-template <typename T, bool INF32>
-static hipError_t launch_stem_wgrad_t(const StemWgradArgs& a, hipStream_t st) {
-  constexpr int PS = Elem<T>::DT == DT_BF16 ? 32 : 16;
+template <typename T, bool INF32, bool POOL>
+static hipError_t launch_stem_wgrad_t(const StemWgradArgs& a, const BnBwdArgs& b, hipStream_t st) {
   const int th = cdiv(a.OH, TH), tw = cdiv(a.OW, TW);
   const int ntiles = a.N * th * tw;
   const size_t lds = 2 * (TH * TW * 64 * sizeof(T) + HR * HC * 4 * sizeof(T));
-  auto kern = stem_wgrad_kernel<T, INF32>;
+  auto kern = stem_wgrad_kernel<T, INF32, POOL>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -496,14 +598,23 @@ static hipError_t launch_stem_wgrad_t(const StemWgradArgs& a, hipStream_t st) {
   }
   int grid = ntiles < 768 ? ntiles : 768;
   f32x4_t* slabs = (Elem<T>::DT == DT_BF16 && grid > 16) ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t))) : nullptr;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, th, tw, ntiles, slabs);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, b, th, tw, ntiles, slabs);
   if (slabs) hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3(14, cdiv(grid, 16)), dim3(256), 0, st, slabs, a.dw, grid);
   return hipGetLastError();
 }
 
 hipError_t launch_stem_wgrad(int dtype, const StemWgradArgs& a, hipStream_t st) {
-  if (dtype == DT_BF16) return a.in_f32 ? launch_stem_wgrad_t<bf16_t, true>(a, st) : launch_stem_wgrad_t<bf16_t, false>(a, st);
-  return a.in_f32 ? launch_stem_wgrad_t<float, true>(a, st) : launch_stem_wgrad_t<float, false>(a, st);
+  const BnBwdArgs b{};
+  if (dtype == DT_BF16) return a.in_f32 ? launch_stem_wgrad_t<bf16_t, true, false>(a, b, st) : launch_stem_wgrad_t<bf16_t, false, false>(a, b, st);
+  return a.in_f32 ? launch_stem_wgrad_t<float, true, false>(a, b, st) : launch_stem_wgrad_t<float, false, false>(a, b, st);
+}
+
+// conv1 wgrad with the max-pool + ReLU + bn0 backward apply pass computed on the fly (b: a pool-form descriptor whose reduce
+// pass has run; b.dx is not written)
+hipError_t launch_stem_wgrad_pool(int dtype, const StemWgradArgs& a, const BnBwdArgs& b, hipStream_t st) {
+  if (!b.pool_dy || !b.pool_argmax || !b.x || b.C != 64 || b.pH != a.OH || b.pW != a.OW || b.g_in_reduce || b.gout) return hipErrorInvalidValue;
+  if (dtype == DT_BF16) return a.in_f32 ? launch_stem_wgrad_t<bf16_t, true, true>(a, b, st) : launch_stem_wgrad_t<bf16_t, false, true>(a, b, st);
+  return a.in_f32 ? launch_stem_wgrad_t<float, true, true>(a, b, st) : launch_stem_wgrad_t<float, false, true>(a, b, st);
 }
 
 }  // namespace sslcr

@@ -181,6 +181,35 @@ def stem_wgrad(x_nchw, dy, dw, *, x2=None):
     L.check(L.lib().sslcr_stem_wgrad(_dt(dy), d, L.stream_ptr()))
 
 
+def stem_wgrad_pool(x_nchw, dw, raw, scale, shift, mean, invstd, pool, *, x2=None, count=None, dgamma=None, dbeta=None):
+    """conv1 wgrad straight from the pooled gradient: pool = (pooled_dy, argmax[, pooled y]); raw = conv1's output.  Runs the
+    pool-form BatchNorm-backward reduce pass, then the fused apply + wgrad kernel.  -> sums[2,64] fp64"""
+    _chk(x_nchw, dw, raw, scale, shift, mean, invstd, x2, dgamma, dbeta)
+    N, _, H, W = x_nchw.shape
+    n_split = 0
+    if x2 is not None:
+        n_split, N = N, N + x2.shape[0]
+    _, OH, OW, Cn = raw.shape
+    pixels = raw.numel() // Cn
+    sums = torch.zeros((2, Cn), dtype=torch.float64, device=raw.device)
+    pdy, pam = pool[0], pool[1]
+    _chk(pdy, pam)
+    b = L.BnBwdDesc(None, L.ptr(raw), None, L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(sums),
+                    None, None, pixels, Cn, 1, float(count if count is not None else pixels),
+                    L.ptr(pdy), L.ptr(pam), OH, OW, pdy.shape[1], pdy.shape[2], None, 0)
+    if len(pool) > 2 and pool[2] is not None:
+        _chk(pool[2])
+        b.pool_y = L.ptr(pool[2])
+    if dgamma is not None:
+        b.dgamma, b.dbeta, b.pg_scale = L.ptr(dgamma), L.ptr(dbeta), 1.0
+    # the reduce pass of the pool form never touches dx; the C-ABI check wants the pointer for the plain form only
+    L.check(L.lib().sslcr_bn_bwd_reduce(_dt(raw), b, L.stream_ptr()))
+    w = L.StemWgradDesc(L.ptr(x_nchw), None, L.ptr(dw), N, H, W, OH, OW, int(x_nchw.dtype == torch.float32),
+                        L.ptr(x2), int(n_split))
+    L.check(L.lib().sslcr_stem_wgrad_pool(_dt(raw), w, b, L.stream_ptr()))
+    return sums
+
+
 def bn_finalize(partials, count, gamma, beta, *, running_mean=None, running_var=None, nbt=None, momentum=0.1,
                 eps=1e-5, replay=1):
     """partial rows [rows,2,C] -> (scale, shift, mean, invstd); running stats updated in place `replay` times."""

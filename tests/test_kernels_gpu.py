@@ -313,6 +313,54 @@ def test_stem_two_segment_input(shape, split, in_u8, dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("in_u8", [True, False])
+@pytest.mark.parametrize("shape,split", [((3, 64, 64), 0), ((2, 56, 40), 0), ((5, 30, 34), 2), ((1, 256, 256), 0), ((40, 64, 64), 16)])
+def test_stem_wgrad_from_pooled_gradient(shape, split, in_u8, dtype):
+    """sslcr_stem_wgrad_pool: conv1's weight gradient straight from the pooled gradient (max-pool + ReLU + bn0 backward apply on
+    the tile in LDS) -- the same bits as sslcr_bn_bwd_apply -> sslcr_stem_wgrad, whose pieces are pinned against torch above, and
+    against autograd of conv1 -> bn1 -> relu -> maxpool (models/net.py:32,77) directly.  Ragged tiles (OH, OW not multiples of
+    8, 16; odd pooled sizes), the two-segment input, more tiles than workgroups ((40, 64, 64): 1280 tiles over 768)."""
+    K = _k()
+    N, H, W = shape
+    xu = torch.from_numpy(np.random.RandomState(51).randint(0, 256, (N, 3, H, W), dtype=np.uint8))
+    xin = (xu if in_u8 else xu.float()).to(DEV)
+    w = rnd(52, (64, 3, 7, 7), 0.03)
+    gamma, beta = rnd(53, (64,)).abs() + 0.5, rnd(54, (64,))
+    wp, _ = K.pack_stem(w.to(DEV), dtype)
+    raw, stats = K.stem_conv(xin, wp, want_stats=True)
+    OH, OW = raw.shape[1:3]
+    sc, sh, mean, invstd = K.bn_finalize(stats, N * OH * OW, gamma.to(DEV), beta.to(DEV))
+    pooled, am = K.bn_relu_maxpool(raw, sc, sh)
+    dyp = to_dev(q(rnd(55, tuple(pooled.shape)), dtype), dtype)
+    # two launches: apply pass writes dY, wgrad reads it
+    dx, sums_a, _ = K.bn_bwd(None, raw, sc, sh, mean, invstd, relu_from_x=True, pool=(dyp, am, pooled))
+    dw_a = torch.zeros((64, 3, 7, 7), dtype=torch.float32, device=DEV)
+    K.stem_wgrad(xin, dx, dw_a)
+    dg_a, db_a = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    K.bn_param_grads(sums_a, invstd, dg_a, db_a)
+    # one launch
+    dw_b = torch.zeros_like(dw_a)
+    dg_b, db_b = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    a, b = (xin[:split].contiguous(), xin[split:].contiguous()) if split else (xin, None)
+    sums_b = K.stem_wgrad_pool(a, dw_b, raw, sc, sh, mean, invstd, (dyp, am, pooled), x2=b, dgamma=dg_b, dbeta=db_b)
+    assert torch.equal(sums_a, sums_b)
+    # same tile -> workgroup assignment and MFMA order; the only freedom is the order of the fold's fp32 atomics
+    close(dw_b, dw_a.cpu(), 2e-6, "fused stem wgrad vs apply + wgrad")
+    close(dg_b, dg_a.cpu(), 1e-6, "dgamma"); close(db_b, db_a.cpu(), 1e-6, "dbeta")
+    # and against autograd of bn1 -> relu -> maxpool on the conv output the kernels saw (in bf16 mode the rounded one: the
+    # argmax / ReLU pattern of a separately computed fp32 convolution differs in a few per cent of the windows), then conv1's wgrad
+    leaf = R.nchw(raw.float().cpu()).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    out = F.max_pool2d(F.relu(F.batch_norm(leaf, None, None, gr, br, True, 0.1, 1e-5)), 3, 2, 1)
+    out.backward(R.nchw(dyp.float().cpu()))
+    wantw = torch.nn.grad.conv2d_weight(xu.float(), (64, 3, 7, 7), leaf.grad, 2, 3)
+    t = 3e-4 if dtype == 0 else 5e-2       # bf16: dY is rounded to bf16 ahead of the wgrad MFMAs (2.8e-2 measured at N = 40)
+    close(dw_b, wantw, t, "fused stem wgrad vs autograd")
+    close(dg_b, gr.grad, t, "dgamma vs autograd")
+    close(db_b, br.grad, t, "dbeta vs autograd")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("hw", [(16, 16), (15, 13)])          # odd sizes: ragged 2x2 blocks / pooling windows at the border
 def test_bn_forward_chain(hw, dtype):
     """conv stats -> finalize (x3 replay) -> bn_act / pool, against F.batch_norm train mode."""
