@@ -171,7 +171,8 @@ typedef struct sslcr_bn_bwd_desc {
   void* dx; void* gout;
   size_t pixels; int C; int relu_from_x; double count;
   const void* pool_dy;    /* optional: dy is not given directly but through maxpool3x3/2 pad 1 -- pooled gradient [N][pOH][pOW][C] ... */
-  const uint8_t* pool_argmax;   /* ... and the argmax codes recorded by sslcr_bn_relu_maxpool; x is then [N][pH][pW][C] */
+  const uint8_t* pool_argmax;   /* ... and the argmax codes recorded by sslcr_bn_relu_maxpool (window position 0..8; 9 = maximum not
+                                   positive, no gradient); x is then [N][pH][pW][C] */
   int pH, pW, pOH, pOW;
   const void* pool_y;     /* optional with pool_dy: the max-pool OUTPUT saved by the forward, [N][pOH][pOW][C].  With it the reduce
                              pass reads only the pooled tensors: a pooled gradient lands on exactly one input pixel, whose

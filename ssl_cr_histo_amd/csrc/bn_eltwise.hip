@@ -156,6 +156,8 @@ hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ stem: maxpool3x3/2 p1 over relu(bn(x)), with argmax
+// argmax code = window position r * 3 + s of the first maximum, or 9 where the maximum is not positive: the ReLU in front of
+// the pool passes no gradient into such a window (torch: relu'(x <= 0) = 0), so the backward kernels need no ReLU test.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs a) {
   constexpr int EPC = Elem<T>::EPC;
@@ -193,6 +195,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs 
       }
     }
     st16_nt(y + i * 16, Elem<T>::pack(best));
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) arg[e] = best[e] > 0.f ? arg[e] : 9;      // code 9: no pixel of this window receives gradient
     if (a.argmax) {
       uint8_t* ap = a.argmax + i * EPC;
       if (EPC == 8) {
@@ -253,6 +257,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(const PoolFwd
       }
       const size_t i = ((size_t)r * a.OW + ow) * cols + col;
       st16_nt(reinterpret_cast<char*>(a.y) + i * 16, Elem<T>::pack(best));
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) arg[e] = best[e] > 0.f ? arg[e] : 9;    // code 9: no pixel of this window receives gradient
       if (a.argmax) {
         uint8_t* ap = a.argmax + i * EPC;
         if (EPC == 8) {

@@ -8,6 +8,7 @@
 // carry zero weights: 147 useful of 224 MACs).  Workgroups are persistent over tiles: the 28 KiB packed weight block
 // is staged once, and BatchNorm (sum, sumsq) partials are accumulated in registers across tiles.
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace sslcr {
 
@@ -24,8 +25,9 @@ static int stem_grid(int N, int OH, int OW) {
 int stem_partials_rows(const StemArgs& a) { return stem_grid(a.N, a.OH, a.OW) * 4; }
 
 template <typename T, bool INF32>
-__device__ __forceinline__ void stem_load_halo(T* halo, const void* xv, int n, int H, int W, int hi0, int wi0) {
-  for (int idx = threadIdx.x; idx < 3 * HR * HC; idx += 256) {
+__device__ __forceinline__ void stem_load_halo(T* halo, const void* xv, int n, int H, int W, int hi0, int wi0, int tid = threadIdx.x,
+                                               int nthreads = 256) {
+  for (int idx = tid; idx < 3 * HR * HC; idx += nthreads) {
     const int c = idx / (HR * HC), rem = idx - c * (HR * HC);
     const int rr = rem / HC, cc = rem - rr * HC;
     const int h = hi0 + rr, w = wi0 + cc;
@@ -84,9 +86,8 @@ __device__ __forceinline__ void stem_commit(T* halo, const float (&pv)[STEM_NEL]
 // colour plane = 4 pixels x 3 channels, and writes them as four 8-byte (c0,c1,c2,0) pixels.  12 bytes per load-triple and
 // 4 LDS stores per thread per tile instead of 10 byte loads + 10 two-byte stores with per-element address arithmetic.
 struct StemRaw { uint32_t d[3]; };
-__device__ __forceinline__ StemRaw stem_issue4(const void* xv, int n, int H, int W, int hi0, int wi0) {
+__device__ __forceinline__ StemRaw stem_issue4(const void* xv, int n, int H, int W, int hi0, int wi0, int tid = threadIdx.x) {
   StemRaw r{{0u, 0u, 0u}};
-  const int tid = threadIdx.x;
   if (tid < HR * 10) {
     const int rr = tid / 10, d = tid - rr * 10;
     const int h = hi0 + rr, w = wi0 - 1 + 4 * d;
@@ -100,8 +101,7 @@ __device__ __forceinline__ StemRaw stem_issue4(const void* xv, int n, int H, int
   return r;
 }
 template <typename T>
-__device__ __forceinline__ void stem_commit4(T* halo, const StemRaw& r) {
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void stem_commit4(T* halo, const StemRaw& r, int tid = threadIdx.x) {
   if (tid >= HR * 10) return;
   const int rr = tid / 10, d = tid - rr * 10;
 #pragma unroll
@@ -567,6 +567,348 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
   }
 }
 
+// ---- bf16 pool form, role-split (the fp32 parity mode keeps the POOL instantiation above: its tiles do not fit three stages)
+// The apply-pass arithmetic is ~570 VALU instructions per (2x2 block, chunk) item against 56 MFMAs per wave and tile: run one
+// after the other in the same wave (above) neither the matrix pipe nor the VALU is busy half the time.  Here a workgroup is
+// 12 waves: waves 0-3 ("matrix") stage the tile by DMA (global_load_lds: no registers, issued two tiles ahead), stage the image
+// halo and run the MFMAs; waves 4-11 ("apply") turn the raw staged tile -- conv output x, pooled gradient windows, argmax codes
+// -- into dY IN PLACE over x, one tile ahead of the MFMAs.  Three stages rotate: dY(t) under the MFMAs | raw(t+1) under the
+// apply pass | DMA(t+2) in flight; one barrier per tile.
+typedef const __attribute__((address_space(1))) void* stem_gptr_t;
+typedef __attribute__((address_space(3))) void* stem_lptr_t;
+constexpr int P2_XB = TH * TW * 128;                  // x / dY tile: [pixel][64 bf16]
+constexpr int P2_WIN = (TH / 2 + 1) * (TW / 2 + 1);   // 45 pooling windows touch the tile
+constexpr int P2_WB = 384 * 16;                       // 45 x 128 B of pooled gradient, padded to 6 wave-loads
+constexpr int P2_AB = 192 * 16;                       // 45 x 64 B of argmax codes, padded to 3 wave-loads
+constexpr int P2_DUMP = P2_XB + P2_WB + P2_AB;       // 1 KiB nobody reads: target of the loads that pad every wave to 7 per tile
+constexpr int P2_STAGE = P2_DUMP + 1024;
+constexpr int P2_NS = 5;
+constexpr int P2_HBUF = HR * HC * 4 * 2;
+
+// LDS transpose read as inline asm.  Through the intrinsic, the compiler's wait-count pass (no usable memory operand on it) puts
+// s_waitcnt vmcnt(0) in front of every such read while ANY global_load_lds is outstanding -- which drains the three tiles of DMA
+// this kernel keeps in flight (plain ds_read_b128 after global_load_lds, conv_dma.hip, does not get that wait).  The asm is
+// opaque to that pass, so the LDS counter is handled by hand next to the reads (see the MFMA loop).
+template <int OFF>
+__device__ __forceinline__ u32x2_t p2_tr16(uint32_t addr) {
+  u32x2_t v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ uint32_t p2_lds_addr(const void* p) {
+  return (uint32_t)(size_t)(__attribute__((address_space(3))) const char*)(const char*)p;
+}
+// Workgroup barrier that leaves the vector-memory counter alone: __syncthreads() is a workgroup-scope fence, which the compiler
+// lowers to s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier -- and vmcnt(0) here means "wait for the three tiles of DMA in flight".
+// What crosses this barrier between waves is LDS data only; the DMA writes it publishes were waited for explicitly.
+__device__ __forceinline__ void p2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#define P2_BOFF(f) ((((f) >> 1) * HC + ((f) & 1) * 4) * 8)
+__device__ __forceinline__ bf16x8_t p2_frag(const u32x2_t& lo, const u32x2_t& hi) {
+  return __builtin_bit_cast(bf16x8_t, u32x4_t{lo[0], lo[1], hi[0], hi[1]});
+}
+
+template <bool INF32>
+__global__ __launch_bounds__(768) void stem_wgrad_pool2_kernel(const StemWgradArgs a, const BnBwdArgs b, int tiles_h, int tiles_w, int ntiles,
+                                                               f32x4_t* partials) {
+  using T = bf16_t;
+  constexpr int RB = 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const halo_base = smem + P2_NS * P2_STAGE;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool matrix = wave < 4;
+  const int li = lane & 15, g = lane >> 4;
+  const bool fast = !INF32 && (a.W & 3) == 0;
+  for (int i = tid; i < 2 * P2_HBUF / 4; i += 768) reinterpret_cast<uint32_t*>(halo_base)[i] = 0u;
+
+  // ---- apply role (8 waves): this thread's item is (2x2 pixel block blk, 4 channels = half a 16-byte chunk) of every tile
+  const int pt = tid >= 256 ? tid - 256 : 0;
+  const int cq = pt & 15, blk = pt >> 4;           // channel quad 0..15, block 0..31
+  const int lh = 2 * (blk >> 3), lw = 2 * (blk & 7);
+  float cA[4], cB[4], cC[4];
+  if (!matrix) {
+    const float invM = (float)(1.0 / b.count);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = cq * 4 + e;
+      const float is = b.invstd[c], sc = b.scale[c];
+      const float m0 = (float)b.sums[c] * invM, m1 = (float)b.sums[64 + c] * invM;
+      cA[e] = sc;
+      cB[e] = -sc * is * is * m1;
+      cC[e] = -sc * m0 - cB[e] * b.mean[c];
+    }
+    if (blockIdx.x == 0 && b.dgamma && b.dbeta && pt < 64) {          // affine gradients, as workgroup 0 of the apply pass does
+      b.dgamma[pt] += (float)(b.sums[64 + pt] * (double)b.invstd[pt] * (double)b.pg_scale);
+      b.dbeta[pt] += (float)(b.sums[pt] * (double)b.pg_scale);
+    }
+  }
+  // No ReLU test here: sslcr_bn_relu_maxpool records code 9 ("nobody") for a window whose maximum is not positive, and the pixel
+  // a live window names has y = that maximum > 0.  EDGE = the tile touches the border of the map (ragged tile, or its last
+  // window row / column lies outside the pooled map): validity by select; interior tiles skip those selects.
+  auto apply = [&](int tile, char* st, auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    const int rem = tile % (tiles_h * tiles_w);
+    const int ho0 = (rem / tiles_w) * TH, wo0 = (rem % tiles_w) * TW;
+    u32x2_t dv[4], xv[4];
+    uint32_t am[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int win = ((lh >> 1) + (q >> 1)) * (TW / 2 + 1) + (lw >> 1) + (q & 1);
+      dv[q] = *reinterpret_cast<const u32x2_t*>(st + P2_XB + win * RB + cq * 8);
+      am[q] = *reinterpret_cast<const uint32_t*>(st + P2_XB + P2_WB + win * 64 + cq * 4);
+      xv[q] = *reinterpret_cast<const u32x2_t*>(st + ((lh + (q >> 1)) * TW + lw + (q & 1)) * RB + cq * 8);
+    }
+    float dw[4][4];
+    uint32_t cd[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      u32x2_t v = dv[q];
+      if constexpr (EDGE) {
+        const bool wok = ((ho0 + lh) >> 1) + (q >> 1) < b.pOH && ((wo0 + lw) >> 1) + (q & 1) < b.pOW;
+        v[0] = wok ? v[0] : 0u; v[1] = wok ? v[1] : 0u;
+      }
+      dw[q][0] = bf_lo(v[0]); dw[q][1] = bf_hi(v[0]); dw[q][2] = bf_lo(v[1]); dw[q][3] = bf_hi(v[1]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cd[q][e] = (am[q] >> (8 * e)) & 0xffu;
+    }
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+      for (int pj = 0; pj < 2; ++pj) {
+        const u32x2_t xw = xv[pi * 2 + pj];
+        const float xf[4] = {bf_lo(xw[0]), bf_hi(xw[0]), bf_lo(xw[1]), bf_hi(xw[1])};
+        float gg[4] = {0.f, 0.f, 0.f, 0.f}, d[4];
+#pragma unroll
+        for (int di = 0; di <= pi; ++di)
+#pragma unroll
+          for (int dj = 0; dj <= pj; ++dj) {
+            const uint32_t code = (uint32_t)((pi - 2 * di + 1) * 3 + (pj - 2 * dj + 1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gg[e] += cd[di * 2 + dj][e] == code ? dw[di * 2 + dj][e] : 0.f;
+          }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = fmaf(cA[e], gg[e], fmaf(cB[e], xf[e], cC[e]));
+        if constexpr (EDGE) {
+          const bool pok = ho0 + lh + pi < a.OH && wo0 + lw + pj < a.OW;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) d[e] = pok ? d[e] : 0.f;
+        }
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        u32x2_t o;                                         // hardware RNE pack: the same bits as Elem<bf16_t>::pack for finite values
+        o[0] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{d[0], d[1]}, bf16x2_t));
+        o[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{d[2], d[3]}, bf16x2_t));
+        *reinterpret_cast<u32x2_t*>(st + ((lh + pi) * TW + lw + pj) * RB + cq * 8) = o;
+      }
+  };
+  auto apply_tile = [&](int tile, char* st) {
+    const int rem = tile % (tiles_h * tiles_w);
+    const int ho0 = (rem / tiles_w) * TH, wo0 = (rem % tiles_w) * TW;
+    const bool interior = ho0 + TH <= a.OH && wo0 + TW <= a.OW && (ho0 >> 1) + TH / 2 < b.pOH && (wo0 >> 1) + TW / 2 < b.pOW;
+    if (interior) apply(tile, st, std::false_type{});
+    else apply(tile, st, std::true_type{});
+  };
+
+  // ---- matrix role: DMA of a raw tile into a stage (25 wave-loads of 1 KiB over the 4 waves), image halo, MFMAs
+  const char* const xg = reinterpret_cast<const char*>(b.x);
+  const char* const dyg = reinterpret_cast<const char*>(b.pool_dy);
+  const char* const amg = reinterpret_cast<const char*>(b.pool_argmax);
+  // per-lane byte offsets of this wave's 7 loads inside an interior tile (tile-invariant: the tile only moves a scalar base)
+  int woff[2], aoff;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int win = ((wave + 4 * i) * 64 + lane) >> 3;
+    win = win < P2_WIN ? win : P2_WIN - 1;
+    woff[i] = ((win / (TW / 2 + 1)) * b.pOW + win % (TW / 2 + 1)) * 128 + (lane & 7) * 16;
+  }
+  {
+    int win = (wave * 64 + lane) >> 2;
+    win = win < P2_WIN ? win : P2_WIN - 1;
+    aoff = ((win / (TW / 2 + 1)) * b.pOW + win % (TW / 2 + 1)) * 64 + (lane & 3) * 16;
+  }
+  auto dma = [&](int tile, char* st) {
+    const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
+    const int ho0 = (rem / tiles_w) * TH, wo0 = (rem % tiles_w) * TW;
+    const bool interior = ho0 + TH <= a.OH && wo0 + TW <= a.OW && (ho0 >> 1) + TH / 2 < b.pOH && (wo0 >> 1) + TW / 2 < b.pOW;
+    if (interior) {
+      // no clamping anywhere in the tile: uniform base + the precomputed lane offset (the address arithmetic of the general
+      // form below, ~40 VALU instructions per load, was half of this role's instruction stream)
+      const char* xt = xg + (((size_t)n * a.OH + ho0) * a.OW + wo0) * 128;
+      const char* dt = dyg + (((size_t)n * b.pOH + (ho0 >> 1)) * b.pOW + (wo0 >> 1)) * 128;
+      const char* at = amg + (((size_t)n * b.pOH + (ho0 >> 1)) * b.pOW + (wo0 >> 1)) * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = wave + 4 * i;
+        __builtin_amdgcn_global_load_lds((stem_gptr_t)(xt + (size_t)(j >> 1) * a.OW * 128 + (j & 1) * 1024 + (uint32_t)(lane * 16)),
+                                         (stem_lptr_t)(st + j * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int l = wave + 4 * i;
+        __builtin_amdgcn_global_load_lds((stem_gptr_t)(dt + (uint32_t)woff[i]), (stem_lptr_t)(st + (l < 6 ? P2_XB + l * 1024 : P2_DUMP)), 16, 0, 0);
+      }
+      __builtin_amdgcn_global_load_lds((stem_gptr_t)(at + (uint32_t)aoff), (stem_lptr_t)(st + (wave < 3 ? P2_XB + P2_WB + wave * 1024 : P2_DUMP)), 16, 0, 0);
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                 // x: wave-load j = 8 pixels of tile row j/2
+      const int j = wave + 4 * i;
+      const int h = ho0 + (j >> 1), w = wo0 + (j & 1) * 8 + (lane >> 3);
+      const int hc = h < a.OH ? h : a.OH - 1, wc = w < a.OW ? w : a.OW - 1;
+      const char* src = xg + ((((size_t)n * a.OH + hc) * a.OW + wc) * 8 + (lane & 7)) * 16;
+      __builtin_amdgcn_global_load_lds((stem_gptr_t)src, (stem_lptr_t)(st + j * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                 // pooled gradient: slot = (window, chunk), 45 x 8 of 384; l = 6, 7 pad
+      const int l = wave + 4 * i;
+      int win = (l * 64 + lane) >> 3;
+      win = win < P2_WIN ? win : P2_WIN - 1;
+      const int oh = (ho0 >> 1) + win / (TW / 2 + 1), ow = (wo0 >> 1) + win % (TW / 2 + 1);
+      const int ohc = oh < b.pOH ? oh : b.pOH - 1, owc = ow < b.pOW ? ow : b.pOW - 1;
+      const char* src = dyg + ((((size_t)n * b.pOH + ohc) * b.pOW + owc) * 8 + (lane & 7)) * 16;
+      __builtin_amdgcn_global_load_lds((stem_gptr_t)src, (stem_lptr_t)(st + (l < 6 ? P2_XB + l * 1024 : P2_DUMP)), 16, 0, 0);
+    }
+    {                                             // argmax codes: slot = (window, quarter), 45 x 4 of 192; wave 3 pads
+      int win = (wave * 64 + lane) >> 2;
+      win = win < P2_WIN ? win : P2_WIN - 1;
+      const int oh = (ho0 >> 1) + win / (TW / 2 + 1), ow = (wo0 >> 1) + win % (TW / 2 + 1);
+      const int ohc = oh < b.pOH ? oh : b.pOH - 1, owc = ow < b.pOW ? ow : b.pOW - 1;
+      const char* src = amg + ((((size_t)n * b.pOH + ohc) * b.pOW + owc) * 4 + (lane & 3)) * 16;
+      __builtin_amdgcn_global_load_lds((stem_gptr_t)src, (stem_lptr_t)(st + (wave < 3 ? P2_XB + P2_WB + wave * 1024 : P2_DUMP)), 16, 0, 0);
+    }
+  };
+  // image halo: by the apply waves (their vector-memory counter carries nothing else, so waiting for these loads never
+  // touches the DMA queue of the matrix waves), issued ahead of the tile's apply pass and committed after it
+  auto halo_issue = [&](int tile) -> StemRaw {
+    if (!fast || tile >= ntiles) return StemRaw{{0u, 0u, 0u}};
+    int n = tile / (tiles_h * tiles_w);
+    const int rem = tile - n * tiles_h * tiles_w;
+    const void* xseg = stem_seg(a, n);
+    return stem_issue4(xseg, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3, pt);
+  };
+  auto halo_commit = [&](int tile, int buf, const StemRaw& raw) {
+    T* hl = reinterpret_cast<T*>(halo_base + buf * P2_HBUF);
+    if (fast) {
+      stem_commit4<T>(hl, raw, pt);
+    } else {
+      int n = tile / (tiles_h * tiles_w);
+      const int rem = tile - n * tiles_h * tiles_w;
+      const void* xseg = stem_seg(a, n);
+      stem_load_halo<T, INF32>(hl, xseg, n, a.H, a.W, 2 * (rem / tiles_w) * TH - 3, 2 * (rem % tiles_w) * TW - 3, pt, 512);
+    }
+  };
+  auto stage = [&](int k) -> char* { return smem + k * P2_STAGE; };
+
+  const int t0 = blockIdx.x, gs = gridDim.x;
+  __syncthreads();                    // halo zero fill
+  if (matrix) {
+    if (t0 < ntiles) dma(t0, stage(0));
+    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+  } else if (t0 < ntiles) {
+    const StemRaw r0 = halo_issue(t0);
+    halo_commit(t0, 0, r0);
+  }
+  __syncthreads();
+  if (matrix) {
+#pragma unroll
+    for (int k = 1; k < P2_NS - 1; ++k)
+      if (t0 + k * gs < ntiles) dma(t0 + k * gs, stage(k));
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+  } else if (t0 < ntiles) {
+    apply_tile(t0, stage(0));
+  }
+  __syncthreads();
+  // One loop per role, the same number of barriers in each: with the roles as two branches of one loop body the accumulators
+  // of the matrix waves (56 registers) stay allocated through the apply code and the kernel does not fit 3 waves per SIMD.
+  if (!matrix) {
+    int cur = 0, i5 = 0;              // i5 = iteration mod 5: dY(t) in stage i5, raw(t+1) in i5+1, DMA(t+4) into i5+4
+    for (int tile = t0; tile < ntiles; tile += gs) {
+      const int nxt = tile + gs;
+      if (nxt < ntiles) {
+        const StemRaw r = halo_issue(nxt);
+        apply_tile(nxt, stage(i5 + 1 < P2_NS ? i5 + 1 : 0));
+        halo_commit(nxt, cur ^ 1, r);
+      }
+      p2_barrier();
+      cur ^= 1;
+      i5 = i5 + 1 < P2_NS ? i5 + 1 : 0;
+    }
+    return;
+  }
+  f32x4_t acc[14];
+#pragma unroll
+  for (int f = 0; f < 14; ++f) acc[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  int cur = 0, i5 = 0;
+  for (int tile = t0; tile < ntiles; tile += gs) {
+    {
+      const int nx4 = tile + 4 * gs;
+      if (nx4 < ntiles) dma(nx4, stage(i5 + 4 < P2_NS ? i5 + 4 : i5 + 4 - P2_NS));
+      const char* sA = stage(i5);
+      const char* halo = halo_base + cur * P2_HBUF;
+#pragma unroll 1
+      for (int step = 0; step < TH * TW / 32; ++step) {
+        // A: dY^T, kouts 16*wave + li, pixels 8g..8g+7; B: this lane's source pixels j = li>>2 (+4), feature quad li&3
+        const uint32_t pa = p2_lds_addr(sA + step * 32 * RB + (8 * g + (li >> 2)) * RB + (16 * wave + (li & 3) * 4) * 2);
+        const int p0 = step * 32 + 8 * g + (li >> 2), p1 = p0 + 4;
+        const uint32_t q0 = p2_lds_addr(halo + ((2 * (p0 / TW) * HC + 2 * (p0 % TW) + (li & 3)) * 4) * 2);
+        const uint32_t q1 = p2_lds_addr(halo + ((2 * (p1 / TW) * HC + 2 * (p1 % TW) + (li & 3)) * 4) * 2);
+        u32x2_t alo = p2_tr16<0>(pa), ahi = p2_tr16<4 * RB>(pa);
+        // the 7 MFMA pairs of a step run three register sets deep: while pair k multiplies, the reads of pairs k+1 and k+2 are in
+        // flight (LDS latency ~130 cycles against 32 cycles of MFMA per pair).  LDS reads return in order, so "pair k has
+        // arrived" is s_waitcnt lgkmcnt(<reads issued after it>); the wait names pair k's registers, which orders its MFMAs
+        // behind it
+        u32x2_t x0, x1, x2, x3, y0, y1, y2, y3, z0, z1, z2, z3;
+#define P2_RD(f, r0, r1, r2, r3)                                                                       \
+        r0 = p2_tr16<P2_BOFF(f)>(q0); r1 = p2_tr16<P2_BOFF(f)>(q1);                                    \
+        r2 = p2_tr16<P2_BOFF(f + 1)>(q0); r3 = p2_tr16<P2_BOFF(f + 1)>(q1);
+#define P2_MM(f, r0, r1, r2, r3)                                                                       \
+        acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, p2_frag(r0, r1), acc[f], 0, 0, 0);       \
+        acc[f + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, p2_frag(r2, r3), acc[f + 1], 0, 0, 0);
+#define P2_WAIT(n, r0, r1, r2, r3) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
+        P2_RD(0, x0, x1, x2, x3)
+        P2_RD(2, y0, y1, y2, y3)
+        P2_RD(4, z0, z1, z2, z3)
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(alo), "+v"(ahi), "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+        const bf16x8_t af = p2_frag(alo, ahi);
+        P2_MM(0, x0, x1, x2, x3)   P2_RD(6, x0, x1, x2, x3)
+        P2_WAIT(8, y0, y1, y2, y3) P2_MM(2, y0, y1, y2, y3)   P2_RD(8, y0, y1, y2, y3)
+        P2_WAIT(8, z0, z1, z2, z3) P2_MM(4, z0, z1, z2, z3)   P2_RD(10, z0, z1, z2, z3)
+        P2_WAIT(8, x0, x1, x2, x3) P2_MM(6, x0, x1, x2, x3)   P2_RD(12, x0, x1, x2, x3)
+        P2_WAIT(8, y0, y1, y2, y3) P2_MM(8, y0, y1, y2, y3)
+        P2_WAIT(4, z0, z1, z2, z3) P2_MM(10, z0, z1, z2, z3)
+        P2_WAIT(0, x0, x1, x2, x3) P2_MM(12, x0, x1, x2, x3)
+#undef P2_RD
+#undef P2_MM
+#undef P2_WAIT
+      }
+      // DMA(t+2) -- the apply pass of the next iteration reads it -- has landed: only DMA(t+3) and DMA(t+4), 7 loads each, may
+      // still be out
+      if (nx4 < ntiles) __builtin_amdgcn_s_waitcnt(0x0f70 | 14);   // vmcnt(14)
+      else __builtin_amdgcn_s_waitcnt(0x0f70);
+    }
+    p2_barrier();
+    cur ^= 1;
+    i5 = i5 + 1 < P2_NS ? i5 + 1 : 0;
+  }
+  if (partials) {
+    f32x4_t* sp = partials + (size_t)blockIdx.x * 14 * 256 + tid;
+#pragma unroll
+    for (int f = 0; f < 14; ++f) sp[f * 256] = acc[f];
+    return;
+  }
+#pragma unroll
+  for (int f = 0; f < 14; ++f) {
+    const int r = f >> 1, s = (f & 1) * 4 + (li >> 2), c = li & 3;
+    if (s < 7 && c < 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 16 * wave + 4 * g + j;
+        atomicAdd(a.dw + ((k * 3 + c) * 7 + r) * 7 + s, acc[f][j]);
+      }
+    }
+  }
+}
+
 // dW += sum of the workgroups' slabs: block (x = accumulator vector f, y = chunk of 16 workgroups), thread = the kernel's thread
 __global__ __launch_bounds__(256) void stem_wgrad_fold_kernel(const f32x4_t* __restrict__ partials, float* dw, int nwg) {
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -611,8 +953,34 @@ hipError_t launch_stem_wgrad(int dtype, const StemWgradArgs& a, hipStream_t st) 
 
 // conv1 wgrad with the max-pool + ReLU + bn0 backward apply pass computed on the fly (b: a pool-form descriptor whose reduce
 // pass has run; b.dx is not written)
+template <bool INF32>
+static hipError_t launch_stem_wgrad_pool2(const StemWgradArgs& a, const BnBwdArgs& b, hipStream_t st) {
+  const int th = cdiv(a.OH, TH), tw = cdiv(a.OW, TW);
+  const int ntiles = a.N * th * tw;
+  const size_t lds = P2_NS * P2_STAGE + 2 * P2_HBUF;
+  auto kern = stem_wgrad_pool2_kernel<INF32>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  int grid = ntiles < 256 ? ntiles : 256;          // one 12-wave workgroup per CU (143 KiB of LDS)
+  f32x4_t* slabs = grid > 16 ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t))) : nullptr;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, st, a, b, th, tw, ntiles, slabs);
+  if (slabs) hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3(14, cdiv(grid, 16)), dim3(256), 0, st, slabs, a.dw, grid);
+  return hipGetLastError();
+}
+
+static int stem_pool_form() {                      // SSLCR_STEM_POOL_FORM=1: the single-role kernel in bf16 mode too (A/B runs)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("SSLCR_STEM_POOL_FORM"); v = e ? atoi(e) : 2; }
+  return v;
+}
+
 hipError_t launch_stem_wgrad_pool(int dtype, const StemWgradArgs& a, const BnBwdArgs& b, hipStream_t st) {
   if (!b.pool_dy || !b.pool_argmax || !b.x || b.C != 64 || b.pH != a.OH || b.pW != a.OW || b.g_in_reduce || b.gout) return hipErrorInvalidValue;
+  if (dtype == DT_BF16 && stem_pool_form() == 2) return a.in_f32 ? launch_stem_wgrad_pool2<true>(a, b, st) : launch_stem_wgrad_pool2<false>(a, b, st);
   if (dtype == DT_BF16) return a.in_f32 ? launch_stem_wgrad_t<bf16_t, true, true>(a, b, st) : launch_stem_wgrad_t<bf16_t, false, true>(a, b, st);
   return a.in_f32 ? launch_stem_wgrad_t<float, true, true>(a, b, st) : launch_stem_wgrad_t<float, false, true>(a, b, st);
 }

@@ -472,6 +472,8 @@ def test_bn_relu_maxpool_many_rows(dtype):
         flat = (2 * oh - 1 + am // 3) * W + (2 * ow - 1 + am % 3)
         pos = R.nhwc(ref) > 0
         assert torch.equal(flat[pos], R.nhwc(idx)[pos])
+        # ... and a window whose maximum is not positive carries code 9: the ReLU passes no gradient into it
+        assert bool((am[~pos] == 9).all()) and bool((am[pos] < 9).all())
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
