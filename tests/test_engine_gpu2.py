@@ -489,6 +489,46 @@ def test_wgrad_side_stream_is_the_same_step(workload, dtype):
             assert rel_err(b, a) < (1e-5 if dtype == "fp32" else 1e-3), i          # (fp32 atomics / slab folds in another order)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("workload", ["ssl_cr", "rsp"])
+def test_fused_stem_backward_is_the_same_step(workload, dtype, monkeypatch):
+    """The engine's stem backward (sslcr_stem_wgrad_pool: conv1's weight gradient straight from the pooled gradient, bn0's
+    backward apply pass on the tile in LDS -- role-split kernel in bf16 mode, single-role in fp32) against the two-kernel path it
+    replaced (SSLCR_FUSE_STEM_BWD=0: sslcr_bn_bwd_apply writes the un-pooled gradient, sslcr_stem_wgrad reads it): every gradient
+    of the step, conv1 and bn1 in particular.  Two engines of one process, same batch, parameters held fixed."""
+    from ssl_cr_histo_amd import engine as E
+    hw, nx, nu = 64, 8, 12
+    out = []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("SSLCR_FUSE_STEM_BWD", fuse)
+        eng = E.Engine(DEV, dtype)
+        if workload == "rsp":
+            ms, cs = build("triplet", "mlp", 6, False)
+            xs = [C.u8(7301 + j, (nx, 3, hw, hw)) for j in range(3)]
+            y = C.ints(7310, (nx,), 6)
+            ms.train()
+            st = eng.bind(ms, cs)
+            eng.step_supervised(st, "ce", xs, y, train=True)
+        else:
+            mt, ct = build("finetune", "finetune", 1, True)
+            ms, cs = build("finetune", "finetune", 1, True)
+            freeze(mt, 64)
+            mt.eval()
+            te = eng.bind(mt, ct)
+            x, u_w, u_s = C.u8(7321, (nx, 3, hw, hw)), C.u8(7322, (nu, 3, hw, hw)), C.u8(7323, (nu, 3, hw, hw))
+            ms.train()
+            st = eng.bind(ms, cs)
+            eng.step_ssl_cr(te, st, "mse", x, C.f32(7324, (nx,)), u_w, u_s, 0.7)
+        torch.cuda.synchronize()
+        out.append([st.grad(i).cpu() for i in range(len(st.params))])
+        del st, eng
+    names = [k for k, _ in ms.named_parameters()]
+    assert names[0].endswith("conv1.weight") and "bn1" in names[1]
+    for i, (a, b) in enumerate(zip(out[0], out[1])):
+        # the same dY bits feed the same MFMAs; what differs is the order of the fp32 folds / atomics into conv1.weight
+        assert rel_err(b, a) <= (2e-6 if i > 2 else 1e-5), (i, names[i] if i < len(names) else "head", rel_err(b, a))
+
+
 # ------------------------------------------------------------------------------------------------ f3: slide-sized WSI map
 @pytest.mark.parametrize("dtype", ["fp32", "bf16", "fp8"])
 def test_cam_wsi_slide_sized_map_vs_reference(dtype):

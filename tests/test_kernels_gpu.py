@@ -360,6 +360,34 @@ def test_stem_wgrad_from_pooled_gradient(shape, split, in_u8, dtype):
     close(db_b, br.grad, t, "dbeta vs autograd")
 
 
+def test_stem_wgrad_pool_rejects_foreign_descriptors():
+    """sslcr_stem_wgrad_pool fails loudly (error code + message, nothing launched) on a BatchNorm descriptor that is not this
+    stem's: wrong channel count, map size, missing pooled gradient, or one that asks for the masked gradient as an output."""
+    K = _k()
+    from ssl_cr_histo_amd import _lib as L
+    N, H = 2, 64
+    x = torch.zeros((N, 3, H, H), dtype=torch.uint8, device=DEV)
+    raw = torch.zeros((N, H // 2, H // 2, 64), dtype=torch.float32, device=DEV)
+    pdy = torch.zeros((N, H // 4, H // 4, 64), dtype=torch.float32, device=DEV)
+    am = torch.zeros((N, H // 4, H // 4, 64), dtype=torch.uint8, device=DEV)
+    v = torch.ones(64, device=DEV)
+    sums = torch.zeros((2, 64), dtype=torch.float64, device=DEV)
+    dw = torch.zeros((64, 3, 7, 7), device=DEV)
+
+    def call(**over):
+        b = L.BnBwdDesc(None, L.ptr(raw), None, L.ptr(v), L.ptr(v), L.ptr(v), L.ptr(v), L.ptr(sums), None, None, raw.numel() // 64, 64, 1,
+                        float(raw.numel() // 64), L.ptr(pdy), L.ptr(am), H // 2, H // 2, H // 4, H // 4, None, 0)
+        for k, val in over.items():
+            setattr(b, k, val)
+        w = L.StemWgradDesc(L.ptr(x), None, L.ptr(dw), N, H, H, H // 2, H // 2, 0, None, 0)
+        return L.lib().sslcr_stem_wgrad_pool(0, w, b, L.stream_ptr())
+    assert call() == 0
+    for over in ({"C": 128}, {"pH": H // 2 - 1}, {"pool_dy": None}, {"pool_argmax": None}, {"gout": L.ptr(raw)}, {"pixels": 17}):
+        assert call(**over) != 0, over
+        assert b"stem_wgrad_pool" in L.lib().sslcr_last_error()
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("hw", [(16, 16), (15, 13)])          # odd sizes: ragged 2x2 blocks / pooling windows at the border
 def test_bn_forward_chain(hw, dtype):
