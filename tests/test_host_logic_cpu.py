@@ -82,6 +82,15 @@ def test_script_modules_expose_reference_names():
                 "pretrain_Camelyon16", "pretrain_RSP", "eval_Camelyon_SSL", "eval_BreastPathQ_SSL", "eval_Kather_SSL"):
         m = importlib.import_module("ssl_cr_histo_amd.scripts." + mod)
         assert callable(m.train) and callable(m.validate)
+    # the modules are synthesised from one table (no file per script): `from ... import` forms work as well, unknown names do not
+    from ssl_cr_histo_amd import scripts, steps
+    from ssl_cr_histo_amd.scripts import test_Camelyon16 as t
+    from ssl_cr_histo_amd.scripts.eval_Kather_SSL import train as ktrain
+    assert t.test is steps.camelyon16_test and ktrain is steps.kather_sup_train
+    assert set(scripts.SCRIPTS) == set(scripts.__all__) and all(hasattr(steps, f) for d in scripts.SCRIPTS.values() for f in d.values())
+    import pytest
+    with pytest.raises(ImportError):
+        importlib.import_module("ssl_cr_histo_amd.scripts.eval_Nothing")
     import inspect
     from ssl_cr_histo_amd import steps
     assert list(inspect.signature(steps.bpq_cr_train).parameters) == [
