@@ -75,7 +75,7 @@ def build_nets(device, classes=1, triplet=False):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-CPU_BASELINE_WALL_S = 80.0        # hard bound on the whole leg (the child process is killed at the deadline)
+CPU_BASELINE_WALL_S = 60.0        # hard bound on the whole leg (the child process is killed at the deadline)
 
 
 def cpu_baseline_child(args):
@@ -121,21 +121,27 @@ def cpu_baseline_child(args):
                           "images_per_s": round(patches / med, 2), "s_per_step": round(med, 3), "timed_steps": len(times),
                           "warmup_steps": warm, "patches_per_step": patches}), flush=True)
     ncpu = os.cpu_count() or 1
-    t32 = min(32, ncpu)
-    leg(t32, True, 14.0)
-    leg(t32, False, 8.0)
+    # torch-CPU convolutions on a 34-image batch do not scale with the thread count: measured on the MI355X box's 2 x EPYC 9575F
+    # (256 logical cores) 0.29 s/step at 16 threads, 0.33 at 32, 0.69 at 64, 1.49 at 128, and not one step in 3 min at 256 -- so
+    # the legs of record are 16 and 32 threads, then one single-thread step, then one step each at half and at all logical
+    # cores for as long as the wall bound allows
+    small = [t for t in (16, 32) if t <= ncpu] or [ncpu]
+    for t in small:
+        leg(t, True, 8.0)
+        leg(t, False, 4.0)
     leg(1, False, 0.0, warm=0)              # one single-thread step, no warm-up: order of magnitude per core
-    if ncpu != t32:                         # all logical cores: torch-CPU convolutions on a 34-image batch collapse far below a
-        leg(ncpu, False, 8.0)               # 256-thread host (measured: not one step in 3 min) -- whatever finishes inside the wall
-        leg(ncpu, True, 14.0)
+    for t in (ncpu // 2, ncpu):
+        if t > small[-1]:
+            leg(t, False, 0.0, warm=0)
 
 
 def cpu_baseline(args):
     """The oracle (CPU restatement of the reference step, torch-CPU fp32, proved equal to the reference's train() on the
     committed goldens) timed on this box's host cores: config C4 at b=2, mu=7 (student 20 / teacher 14 images, 34 distinct
     patches per step), full fine-tune, Adam -- FAITHFUL (three backbone passes per image, models/net.py:88-90: what the
-    reference executes) and ALGORITHMIC (one pass), at 32 threads (median of up to 5 timed steps after one warm-up), one single-thread
-    step of the algorithmic variant, then the same two variants at os.cpu_count() threads as far as the wall bound allows.  Bounded: every leg stops adding steps once its
+    reference executes) and ALGORITHMIC (one pass), at 16 and 32 threads (median of up to 5 timed steps after one warm-up), one
+    single-thread step of the algorithmic variant, then one algorithmic step at half and at all logical cores as far as the wall
+    bound allows (more threads are slower on this batch, see cpu_baseline_child).  Bounded: every leg stops adding steps once its
     share is used, and the whole thing runs in a child process that is killed at CPU_BASELINE_WALL_S (legs finished by then
     count).  `value` = the best faithful leg (the reference-equivalent baseline of record)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--image_size", str(args.image_size), "--mu", str(args.mu),
