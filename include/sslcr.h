@@ -152,7 +152,8 @@ typedef struct sslcr_bn_act_desc {      /* y = relu(x*scale+shift [+ res*rscale+
 } sslcr_bn_act_desc;
 int sslcr_bn_act(int dtype, const sslcr_bn_act_desc* d, void* stream);
 
-typedef struct sslcr_pool_fwd_desc {    /* maxpool3x3/2 pad 1 of relu(bn(x))   (K8) */
+typedef struct sslcr_pool_fwd_desc {    /* maxpool3x3/2 pad 1 of relu(bn(x))   (K8); scale = shift = argmax = NULL: plain
+                                           max-pool of x as it is (the eval path: BatchNorm folded into conv1, ReLU in its epilogue) */
   const void* x; const float* scale; const float* shift; void* y; uint8_t* argmax; int N, H, W, C, OH, OW;
 } sslcr_pool_fwd_desc;
 int sslcr_bn_relu_maxpool(int dtype, const sslcr_pool_fwd_desc* d, void* stream);

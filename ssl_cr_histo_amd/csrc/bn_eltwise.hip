@@ -213,6 +213,47 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs 
 // Row form (256 % (C / EPC) == 0, every ResNet width): a workgroup walks output rows (n, oh); a thread keeps its channel
 // chunk, so the index arithmetic is one uniform division per ROW instead of six 64-bit divisions per 16-byte chunk, and the
 // nine window loads are unconditional (clamped address, validity by select) so they are all in flight together.
+// PLAIN (scale == nullptr): x is pooled as it is -- the eval path, where conv1's epilogue already applied the folded BatchNorm and
+// the ReLU.  No affine, no ReLU, no argmax, and no validity selects either: a clamped address re-reads a pixel of the same window,
+// and a duplicate does not change a maximum.  9 x (unpack + max) instead of 9 x (unpack + fma + max + compare + 2 selects).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_rows_kernel(const PoolFwdArgs a) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = a.C / EPC;
+  const int ppp = 256 / cols;
+  const int col = threadIdx.x % cols, pw0 = threadIdx.x / cols;
+  const char* x = reinterpret_cast<const char*>(a.x) + (size_t)col * 16;
+  const int rows = a.N * a.OH;
+  const size_t rowb = (size_t)a.W * a.C * sizeof(T);
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / a.OH, oh = r - n * a.OH;
+    const int h0 = 2 * oh - 1;
+    const char* xn = x + (size_t)n * a.H * rowb;
+    for (int ow = pw0; ow < a.OW; ow += ppp) {
+      const int w0 = 2 * ow - 1;
+      u32x4_t v[9];
+#pragma unroll
+      for (int wi = 0; wi < 9; ++wi) {
+        int h = h0 + wi / 3, w = w0 + wi % 3;
+        h = h < 0 ? 0 : (h >= a.H ? a.H - 1 : h);
+        w = w < 0 ? 0 : (w >= a.W ? a.W - 1 : w);
+        v[wi] = ld16(xn + (size_t)h * rowb + (size_t)w * a.C * sizeof(T));
+      }
+      float best[EPC];
+      Elem<T>::unpack(v[0], best);
+#pragma unroll
+      for (int wi = 1; wi < 9; ++wi) {
+        float f[EPC];
+        Elem<T>::unpack(v[wi], f);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) best[e] = fmaxf(best[e], f[e]);
+      }
+      const size_t i = ((size_t)r * a.OW + ow) * cols + col;
+      st16_nt(reinterpret_cast<char*>(a.y) + i * 16, PackH<T>::run(best));     // (exact: the maximum is one of the inputs)
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(const PoolFwdArgs a) {
   constexpr int EPC = Elem<T>::EPC;
@@ -276,6 +317,13 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(const PoolFwd
 hipError_t launch_bn_relu_maxpool(int dtype, const PoolFwdArgs& a, hipStream_t st) {
   size_t px = (size_t)a.N * a.OH * a.OW;
   const int cols = a.C / (dtype == DT_BF16 ? 8 : 4);
+  if (!a.scale || !a.shift) {          // plain max-pool (capi.cpp admits it only without argmax and for the row form's widths)
+    const int rows = a.N * a.OH;
+    const int grid = rows < 256 * 16 ? rows : 256 * 16;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(maxpool_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(maxpool_rows_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+    return hipGetLastError();
+  }
   if (cols >= 1 && cols <= 256 && 256 % cols == 0) {
     const int rows = a.N * a.OH;
     const int grid = rows < 256 * 16 ? rows : 256 * 16;

@@ -109,6 +109,11 @@ int sslcr_bn_act(int dtype, const sslcr_bn_act_desc* d, void* stream) {
 int sslcr_bn_relu_maxpool(int dtype, const sslcr_pool_fwd_desc* d, void* stream) {
   DT_OK(dtype);
   NEED(d && d->x && d->y, "null");
+  if (!d->scale || !d->shift) {
+    const int cols = d->C / (dtype == SSLCR_BF16 ? 8 : 4);
+    NEED(!d->scale && !d->shift && !d->argmax, "plain max-pool (scale = shift = NULL) records no argmax");
+    NEED(cols >= 1 && cols <= 256 && 256 % cols == 0 && d->C % (dtype == SSLCR_BF16 ? 8 : 4) == 0, "plain max-pool: unsupported channel count");
+  }
   return check(launch_bn_relu_maxpool(dtype, *d, (hipStream_t)stream), "bn_relu_maxpool");
 }
 int sslcr_maxpool_relu_bwd(int dtype, const sslcr_pool_bwd_desc* d, void* stream) {

@@ -682,7 +682,7 @@ int backbone_forward_eval(sslcr_net* n, const void* x, int in_f32, int N, int H,
     TRY(launch_stem(dt, a, st));
     PoolFwdArgs p;
     memset(&p, 0, sizeof(p));
-    p.x = base + o_a0; p.scale = c->ones; p.shift = c->zeros; p.y = base + o_buf[0];
+    p.x = base + o_a0; p.y = base + o_buf[0];            // plain max-pool: the stem's epilogue applied the folded BatchNorm + ReLU
     p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
     TRY(launch_bn_relu_maxpool(dt, p, st));
   }

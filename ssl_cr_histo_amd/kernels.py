@@ -236,11 +236,12 @@ def bn_act(x, scale, shift, *, res=None, rscale=None, rshift=None, relu=True):
 
 
 def bn_relu_maxpool(x, scale, shift):
+    """maxpool3x3/2 pad 1 of relu(scale * x + shift) -> (y, argmax codes); scale = shift = None: plain max-pool of x -> (y, None)."""
     _chk(x, scale, shift)
     N, H, W, Cn = x.shape
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((N, OH, OW, Cn), dtype=x.dtype, device=x.device)
-    am = torch.empty((N, OH, OW, Cn), dtype=torch.uint8, device=x.device)
+    am = torch.empty((N, OH, OW, Cn), dtype=torch.uint8, device=x.device) if scale is not None else None
     d = L.PoolFwdDesc(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(y), L.ptr(am), N, H, W, Cn, OH, OW)
     L.check(L.lib().sslcr_bn_relu_maxpool(_dt(x), d, L.stream_ptr()))
     return y, am

@@ -493,6 +493,9 @@ def test_bn_relu_maxpool_many_rows(dtype):
     act = F.relu(R.nchw(x) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
     ref, idx = F.max_pool2d(act, 3, 2, 1, return_indices=True)
     close(pooled, R.nhwc(ref), 1e-6 if dtype == 0 else 1e-2, "maxpool values")
+    # plain form (the eval path: no affine, no ReLU, no argmax), negative values included: bit-exact, a maximum is one of its inputs
+    plain, none = K.bn_relu_maxpool(to_dev(x, dtype), None, None)
+    assert none is None and torch.equal(plain.float().cpu(), R.nhwc(F.max_pool2d(R.nchw(x), 3, 2, 1)))
     if dtype == 0:
         # the argmax codes (window position r*3+s) point at the element torch picked wherever the maximum is unique
         am = am.cpu().to(torch.int64).reshape(N, H // 2, W // 2, C)
