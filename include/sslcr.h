@@ -19,6 +19,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly the entry points declared between this push and the pop at the end of
+ * the file are exported (tests/test_abi_cpu.py compares `nm -D` with this header) */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define SSLCR_F32 0
 #define SSLCR_BF16 1
@@ -327,7 +332,10 @@ int sslcr_net_create(sslcr_ctx* ctx, const sslcr_net_desc* d, sslcr_net** out);
 int sslcr_net_destroy(sslcr_net* net);
 int sslcr_net_set_requires_grad(sslcr_net* net, const uint8_t* flags);
 /* re-derive the shadow weights from the bound fp32 parameters: mode bit0 = train packs (KRSC + dgrad CRSK),
- * bit1 = eval packs (BatchNorm running stats folded into KRSC weights + bias). Call after any parameter change. */
+ * bit1 = eval packs (BatchNorm running stats folded into KRSC weights + bias). Call after any parameter change.
+ * SSLCR_FP8 contexts: mode 3 also drops the calibrated activation scales -- the first forward of the net in each mode (train,
+ * eval) after sslcr_net_create or after a mode-3 pack runs the backbone TWICE (a calibration pass at scale 1 that only records
+ * amax -- running statistics untouched, synced-BatchNorm all-reduces included -- then the real pass), so time steps after it. */
 int sslcr_net_pack(sslcr_net* net, int mode, void* stream);
 
 /* forward.  x2/x3 only for triplet nets.  train=0: eval-mode BN (folded), nothing saved.  train=1: batch-stat BN,
@@ -338,6 +346,18 @@ int sslcr_net_forward(sslcr_net* net, int train, const void* x1, const void* x2,
  * all-reduces it when a communicator is set. */
 int sslcr_net_backward(sslcr_net* net, const float* dlogits, void* stream);
 int sslcr_net_grad(sslcr_net* net, int param_index, float* out, void* stream);      /* -> PyTorch layout */
+/* diagnostics for the layer-wise backward parity test (tests/test_backward_replay_gpu.py): autograd of one BasicBlock of
+ * torchvision resnet18 (reached from models/net.py:32,77) checked kernel by kernel at the size the step really runs.  With the tap
+ * on, sslcr_net_backward keeps a copy of every block's transient gradient tensors of pass 0; sslcr_net_debug_tensor copies one
+ * tensor of block 0..7 (layer1.0 .. layer4.1) into `out` (device memory, engine storage dtype, NHWC) and reports its dims:
+ *   kind 0 G     = d(block output) * (output > 0)           1 dRaw2 = gradient at conv2's raw output (after bn2 backward)
+ *        2 dAct1 = conv2's dgrad (flags bit 0: bn1's ReLU mask already applied)    3 dRaw1 = gradient at conv1's raw output
+ *        4 dRawD = gradient at the projection conv's raw output                    5 dXin  = gradient at the block input
+ *        6 raw1, 7 raw2, 8 rawd (saved raw conv outputs), 9 y (block output), 10 x (block input)
+ *       11..14 bn1's saved scale, shift, mean, invstd (fp32 [C]; dims = {C,1,1,1})
+ * out == NULL: only dims4 / flags are filled. */
+int sslcr_net_debug_tap(sslcr_net* net, int on);
+int sslcr_net_debug_tensor(sslcr_net* net, int block, int kind, void* out, size_t out_bytes, int* dims4, int* flags, void* stream);
 /* fused multi-tensor update of every requires_grad parameter; state1/state2 = per-parameter optimizer state
  * (exp_avg/exp_avg_sq or momentum_buffer) owned by the caller, NULL entries for frozen parameters */
 int sslcr_net_optimizer_step(sslcr_net* net, const sslcr_opt_desc* o, float* const* state1, float* const* state2, void* stream);
@@ -374,6 +394,9 @@ typedef struct sslcr_sup_desc {
 } sslcr_sup_desc;
 int sslcr_step_supervised(sslcr_net* net, const sslcr_sup_desc* d, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

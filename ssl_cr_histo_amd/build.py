@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsslcr.so")
 SOURCES = ["conv_igemm.hip", "conv_halo.hip", "conv_halo256.hip", "conv_h16.hip", "conv_dma.hip", "conv_fp8.hip", "conv_wgrad.hip", "wgrad_halo.hip","stem.hip", "augment.hip", "bn_eltwise.hip", "heads.hip", "optim.hip",
            "engine.cpp", "capi.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result", "-fvisibility=hidden"]
 
 
 def _stale(out, deps):
@@ -17,6 +17,14 @@ def _stale(out, deps):
         return True
     t = os.path.getmtime(out)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def header_symbols():
+    """the C-ABI entry points, read from include/sslcr.h"""
+    import re
+    with open(os.path.join(os.path.dirname(HERE), "include", "sslcr.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(sslcr_[a-z0-9_]+)\s*\(", text)))
 
 
 def build(force=False, verbose=False):
@@ -41,8 +49,14 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+    # exactly the entry points include/sslcr.h declares are exported: -fvisibility=hidden + the header's visibility push covers
+    # the functions, the version script also makes the compiler-generated kernel handles and template instances local
+    vmap = os.path.join(objdir, "exports.map")
+    with open(vmap, "w") as f:
+        f.write("{ global: " + " ".join(n + ";" for n in header_symbols()) + " local: *; };\n")
     if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl"]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-L/opt/rocm/lib", "-lrccl",
+                                                                                      f"-Wl,--version-script={vmap}"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout)

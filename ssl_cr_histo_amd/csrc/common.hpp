@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace sslcr {
 
 typedef uint16_t bf16_t;                                    // raw bf16 bits

@@ -250,7 +250,7 @@ static hipError_t launch_d(const ConvArgs& a, hipStream_t st) {
   const int M = a.N * a.PH * a.PW;
   const size_t lds = 2 * (BP + BKO) * 128;
   auto kern = conv_dma_kernel<T, BP, BKO>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;

@@ -378,7 +378,7 @@ static hipError_t launch_f8(const ConvArgs& a, const Fp8Args& q, hipStream_t st)
   constexpr int HBUF = ((HP * 128 + 1023) / 1024) * 1024;
   const size_t lds = 2 * HBUF + 3 * 128 * 128 + (XF ? 2 * a.C * sizeof(float) : 0);
   auto kern = conv3x3_fp8_kernel<TW, XF>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;

@@ -509,7 +509,7 @@ static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
                      (a.mask_x ? 3 : 1) * a.K * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   auto kern = conv3x3_h16_kernel<T, BKO, WK, XF, WR>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;

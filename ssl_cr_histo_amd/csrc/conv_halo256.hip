@@ -330,7 +330,7 @@ static hipError_t launch_q(const ConvArgs& a, hipStream_t st, int tile0 = 0, int
   constexpr int TPB = (WK == 2 && !ONE) ? 3 : 1;
   const size_t lds = HP * 128 + 2 * TPB * BKO * 128 + 2 * a.C * sizeof(float);
   auto kern = conv3x3_halo256_kernel<T, TW, BKO, WK, ONE>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;

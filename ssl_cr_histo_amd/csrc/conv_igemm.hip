@@ -260,7 +260,7 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t st) {
   dim3 grid(cdiv(M, BP), a.K / BKO);
   size_t lds = 2 * (BP + BKO) * 128 + 2 * a.C * sizeof(float);
   auto kern = conv_igemm_kernel<T, BP, BKO>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;

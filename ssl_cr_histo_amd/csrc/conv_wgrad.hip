@@ -198,7 +198,7 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
   splits = cdiv(total_steps, sps);
   const size_t lds = 2 * (1 + TAPS) * 4096;
   auto kern = wgrad_kernel<T, TAPS>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;

@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -143,6 +144,7 @@ struct VChan {                      // one per collective stream (0: BatchNorm s
 struct sslcr_vcomm {
   int world = 1;
   VChan ch[2];
+  std::atomic<bool> poisoned{false};   // a rank timed out inside a collective: its call parity is out of step with its peers for good
 };
 
 struct sslcr_ctx {
@@ -213,6 +215,11 @@ struct sslcr_net {
         *dtmp256 = nullptr, *dtmp512 = nullptr, *dcat = nullptr, *scratch = nullptr, *dlogits = nullptr, *logits_t = nullptr;
   int last_N = 0, last_npass = 0;
   bool packed_train = false, packed_eval = false;
+  // sslcr_net_debug_tap: backward keeps copies of each block's transient gradient tensors (pass 0) for the layer-wise replay test
+  bool tap = false;
+  DevBuf tapbuf[8][6];
+  int tapdims[8][6][4] = {};
+  int tap_flags[8] = {};            // bit 0: dAct1 was written with bn1's ReLU mask already applied (mask_x front end of the dgrad)
   std::vector<sslcr_tensor_desc> host_descs;
   std::vector<float*> st1, st2;
   int ndesc = 0, max_n = 0;
@@ -237,6 +244,7 @@ int vcomm_all_reduce(sslcr_ctx* c, int chan, void* buf, size_t count, bool f64, 
   VChan& ch = v->ch[chan];
   const int r = c->rank, W = v->world;
   const size_t bytes = count * (f64 ? 8 : 4);
+  if (v->poisoned) return fail("virtual all-reduce: the communicator was poisoned by an earlier timeout");
   const int ph = (int)(ch.calls[r]++ & 1);
   // the slot is reused every second call: its previous readers (the peers' sum kernels of two calls ago) recorded ev_out then
   for (int q = 0; q < W; ++q)
@@ -261,7 +269,9 @@ int vcomm_all_reduce(sslcr_ctx* c, int chan, void* buf, size_t count, bool f64, 
       ch.cv.notify_all();
     } else if (!ch.cv.wait_for(lk, std::chrono::seconds(120), [&] { return ch.gen != g; })) {
       --ch.arrived;
-      return fail("virtual all-reduce: rank %d waited 120 s for its peers (channel %d)", r, chan);
+      c->vcomm->poisoned = true;          // calls[r] and the slot are already published: every later collective would pair up wrongly
+      ch.cv.notify_all();
+      return fail("virtual all-reduce: rank %d waited 120 s for its peers (channel %d); the communicator is now unusable", r, chan);
     }
   }
   VSrc src;
@@ -978,6 +988,16 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
   int kOut = 0, kXin = 5;
   const int kG = 1, kRaw2 = 2, kAct1 = 3, kRaw1 = 4, kRawD = 6;
   char* dRaw0 = S + (size_t)7 * npass * unit;
+  // debug tap (pass 0 only): slot 0 G, 1 dRaw2, 2 dAct1, 3 dRaw1, 4 dRawD, 5 dXin
+  auto tap = [&](int blk, int slot, const void* src, int n_, int h_, int w_, int c_) -> int {
+    if (!n->tap) return 0;
+    const size_t bytes = (size_t)n_ * h_ * w_ * c_ * es;
+    TRYI(n->tapbuf[blk][slot].ensure(bytes));
+    TRY(hipMemcpyAsync(n->tapbuf[blk][slot].p, src, bytes, hipMemcpyDeviceToDevice, st));
+    int* d4 = n->tapdims[blk][slot];
+    d4[0] = n_; d4[1] = h_; d4[2] = w_; d4[3] = c_;
+    return 0;
+  };
 
   size_t hi_pending = n->goff[60];
   int bucket = 1;
@@ -1021,6 +1041,11 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       } else {
         TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, nullptr, 1));
       }
+      if (p == 0) {
+        TRYI(tap(i, 0, G, N, oh, ow, B.c2.cout));
+        TRYI(tap(i, 1, dRaw2, N, oh, ow, B.c2.cout));
+        if (B.has_ds) TRYI(tap(i, 4, dRawD, N, oh, ow, B.ds.cout));
+      }
       if (!c2_batched) TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st, 0, 0, 0));
       float* b1_rows = nullptr;
       int b1_nrows = 0;
@@ -1038,10 +1063,15 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
           a = m;
         }
         TRY(prof_conv(c, dt,a, st));
+        if (p == 0) {
+          TRYI(tap(i, 2, dAct1, N, oh, ow, B.c2.cin));
+          n->tap_flags[i] = b1_rows ? 1 : 0;
+        }
       }
       TRYI(wg_wait(c, 1, st));
       TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, b1_rows ? 0 : 1, dRaw1, nullptr, opix, (double)opix, st,
                        nullptr, 0, b1_rows, b1_nrows));
+      if (p == 0) TRYI(tap(i, 3, dRaw1, N, oh, ow, B.c1.cout));
     }
     // weight gradients: one launch over the npass * N images (x and dy contiguous across passes)
     if (c2_batched)
@@ -1091,6 +1121,7 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
           s.accumulate = 1;
           TRY(prof_conv(c, dt,s, st));
         }
+        TRYI(tap(i, 5, dXin, N, xh, xw, B.c1.cin));
       }
       const int t = kOut; kOut = kXin; kXin = t;      // ping-pong: this block's input gradient is the next dOut
     }
@@ -1151,7 +1182,6 @@ int net_forward(sslcr_net* n, int train, const void* const* xs, int in_f32, int 
     // fp8 delayed scaling needs one forward to have seen the data: the FIRST forward of a net in a mode runs twice -- a
     // calibration pass at scale 1 (amax recorded, BatchNorm running statistics untouched, outputs overwritten below), then the
     // real one with the scales it produced
-    n->f8_cal[train ? 0 : 1] = true;
     n->f8_calib_pass = true;
     TRYI(alloc_heads(n, N));
     int rc = 0;
@@ -1159,7 +1189,8 @@ int net_forward(sslcr_net* n, int train, const void* const* xs, int in_f32, int 
       rc = train ? backbone_forward_train(n, n->pass[i], xs[i], in_f32, N, H, W, n->triplet ? 1 : 3, st)
                  : backbone_forward_eval(n, xs[i], in_f32, N, H, W, n->dE[i], st);
     n->f8_calib_pass = false;
-    if (rc) return rc;
+    if (rc) return rc;                           // not calibrated: the next forward tries again instead of running at scale 1
+    n->f8_cal[train ? 0 : 1] = true;
   }
   if (n->n8 > 0) TRY(launch_fp8_scale_update(n->f8slots, n->n8, st));      // fp8 delayed scaling: last forward's amax -> this one's scales
   if (train) n->packed_eval = false;               // running statistics are about to change
@@ -1415,6 +1446,8 @@ int sslcr_net_destroy(sslcr_net* n) {
   (void)hipDeviceSynchronize();
   n->shadow.release(); n->grads.release(); n->heads.release(); n->descs.release(); n->f8buf.release();
   for (int i = 0; i < 3; ++i) n->pass[i].mem.release();
+  for (auto& row : n->tapbuf)
+    for (DevBuf& b : row) b.release();
   delete n;
   return 0;
 }
@@ -1438,6 +1471,9 @@ int sslcr_net_pack(sslcr_net* n, int mode, void* stream) {
   }
   if (mode & 1) n->packed_train = true;
   if (mode & 2) n->packed_eval = true;
+  // a full re-pack is what the host asks for after it changed parameters behind the engine's back (load_state_dict, --resume):
+  // the fp8 activation scales were calibrated on the previous weights, so the next forward of each mode calibrates again
+  if (mode == 3) n->f8_cal[0] = n->f8_cal[1] = false;
   return 0;
 }
 
@@ -1452,6 +1488,51 @@ int sslcr_net_forward(sslcr_net* n, int train, const void* x1, const void* x2, c
 int sslcr_net_backward(sslcr_net* n, const float* dlogits, void* stream) {
   if (!n || !dlogits) return fail("sslcr_net_backward: null");
   return net_backward(n, dlogits, (hipStream_t)stream);
+}
+
+int sslcr_net_debug_tap(sslcr_net* n, int on) {
+  if (!n) return fail("sslcr_net_debug_tap: null net");
+  n->tap = on != 0;
+  if (!on)
+    for (auto& row : n->tapbuf)
+      for (DevBuf& b : row) b.release();
+  return 0;
+}
+
+int sslcr_net_debug_tensor(sslcr_net* n, int block, int kind, void* out, size_t out_bytes, int* dims4, int* flags, void* stream) {
+  if (!n || block < 0 || block > 7 || kind < 0 || kind > 14 || !dims4) return fail("sslcr_net_debug_tensor: invalid argument");
+  sslcr_ctx* c = n->ctx;
+  hipStream_t st = (hipStream_t)stream;
+  const BlockL& B = n->blocks[block];
+  const PassState& ps = n->pass[0];
+  if (n->last_npass == 0 || !ps.mem.p) return fail("sslcr_net_debug_tensor: no train-mode forward");
+  const Dims d = make_dims(ps.H, ps.W);
+  const int oh = d.lh[block], ow = d.lw[block];
+  const int xh = block == 0 ? d.ph : d.lh[block - 1], xw = block == 0 ? d.pw : d.lw[block - 1];
+  const void* src = nullptr;
+  size_t esz = c->esz();
+  int dm[4] = {ps.N, oh, ow, B.c2.cout};
+  if (kind <= 5) {
+    if (!n->tap || !n->tapbuf[block][kind].p) return fail("sslcr_net_debug_tensor: nothing tapped for block %d kind %d", block, kind);
+    src = n->tapbuf[block][kind].p;
+    for (int j = 0; j < 4; ++j) dm[j] = n->tapdims[block][kind][j];
+  } else if (kind == 6) { src = ps.blk[block].raw1; dm[3] = B.c1.cout; }
+  else if (kind == 7) { src = ps.blk[block].raw2; }
+  else if (kind == 8) { src = ps.blk[block].rawd; if (!B.has_ds) return fail("sslcr_net_debug_tensor: block %d has no projection", block); }
+  else if (kind == 9) { src = ps.blk[block].y; }
+  else if (kind == 10) { src = block == 0 ? ps.pooled : ps.blk[block - 1].y; dm[1] = xh; dm[2] = xw; dm[3] = B.c1.cin; }
+  else {                        // 11..14: bn1's saved scale, shift, mean, invstd (fp32 [C])
+    const BnSaved& sv = ps.bn[B.b1.bidx];
+    const float* v[4] = {sv.scale, sv.shift, sv.mean, sv.invstd};
+    src = v[kind - 11]; esz = 4; dm[0] = B.b1.C; dm[1] = dm[2] = dm[3] = 1;
+  }
+  for (int j = 0; j < 4; ++j) dims4[j] = dm[j];
+  if (flags) *flags = n->tap_flags[block];
+  if (!out) return 0;
+  const size_t bytes = (size_t)dm[0] * dm[1] * dm[2] * dm[3] * esz;
+  if (out_bytes < bytes) return fail("sslcr_net_debug_tensor: buffer of %zu bytes, tensor has %zu", out_bytes, bytes);
+  TRY(hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToDevice, st));
+  return 0;
 }
 
 int sslcr_net_grad(sslcr_net* n, int pidx, float* out, void* stream) {

@@ -313,7 +313,7 @@ static hipError_t launch_stem_t(const StemArgs& a, hipStream_t st) {
   const int ntiles = a.N * th * tw;
   const size_t lds = 64 * (224 * sizeof(T) + 16) + 2 * HR * HC * 4 * sizeof(T);
   auto kern = stem_fwd_kernel<T, INF32>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
@@ -932,7 +932,7 @@ static hipError_t launch_stem_wgrad_t(const StemWgradArgs& a, const BnBwdArgs& b
   const int ntiles = a.N * th * tw;
   const size_t lds = 2 * (TH * TW * 64 * sizeof(T) + HR * HC * 4 * sizeof(T));
   auto kern = stem_wgrad_kernel<T, INF32, POOL>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
@@ -959,7 +959,7 @@ static hipError_t launch_stem_wgrad_pool2(const StemWgradArgs& a, const BnBwdArg
   const int ntiles = a.N * th * tw;
   const size_t lds = P2_NS * P2_STAGE + 2 * P2_HBUF;
   auto kern = stem_wgrad_pool2_kernel<INF32>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -973,8 +973,7 @@ static hipError_t launch_stem_wgrad_pool2(const StemWgradArgs& a, const BnBwdArg
 }
 
 static int stem_pool_form() {                      // SSLCR_STEM_POOL_FORM=1: the single-role kernel in bf16 mode too (A/B runs)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("SSLCR_STEM_POOL_FORM"); v = e ? atoi(e) : 2; }
+  static const int v = [] { const char* e = getenv("SSLCR_STEM_POOL_FORM"); return e ? atoi(e) : 2; }();
   return v;
 }
 

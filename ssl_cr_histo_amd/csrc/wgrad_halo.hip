@@ -345,30 +345,44 @@ hipError_t launch_wgrad_fold(const void* slabs, float* dw, int C, int gx, int gy
   return hipGetLastError();
 }
 
-// slabs of the launches on one stream (a launch's fold has consumed them before the next launch on that stream writes)
+// slabs of the launches on one stream (a launch's fold has consumed them before the next launch on that stream writes).
+// One entry per stream, 32 entries, least-recently-used eviction: a 33rd stream (virtual-rank tests create a stream per context
+// and drop it) takes over the oldest entry after a device synchronise -- never a silent fall-back to the atomic path, whose
+// summation order differs -- and an evicted or destroyed stream's slab is freed instead of leaking.
 void* wgrad_slabs(hipStream_t st, size_t bytes) {
-  struct Slab { hipStream_t st; void* p; size_t cap; };
-  static Slab slabs[8];
+  struct Slab { hipStream_t st; void* p; size_t cap; unsigned long long used; };
+  constexpr int NSLAB = 32;
+  static Slab slabs[NSLAB];
   static int n = 0;
+  static unsigned long long tick = 0;
   static std::mutex mu;                          // host threads driving different streams
   std::lock_guard<std::mutex> lock(mu);
-  for (int i = 0; i < n; ++i)
-    if (slabs[i].st == st) {
-      if (slabs[i].cap < bytes) {
-        (void)hipStreamSynchronize(st);
-        (void)hipFree(slabs[i].p);
-        slabs[i].p = nullptr; slabs[i].cap = 0;
-        if (hipMalloc(&slabs[i].p, bytes) != hipSuccess) return nullptr;
-        slabs[i].cap = bytes;
-      }
-      return slabs[i].p;
+  Slab* e = nullptr;
+  for (int i = 0; i < n && !e; ++i)
+    if (slabs[i].st == st) e = &slabs[i];
+  if (!e) {
+    if (n < NSLAB) {
+      e = &slabs[n++];
+    } else {
+      e = &slabs[0];
+      for (int i = 1; i < NSLAB; ++i)
+        if (slabs[i].used < e->used) e = &slabs[i];
+      (void)hipDeviceSynchronize();              // the evicted stream may be gone: wait for the device, not for the stream
+      if (e->p) (void)hipFree(e->p);
     }
-  if (n == 8) return nullptr;                    // more streams than slots: that launch falls back to atomics
-  Slab s{st, nullptr, 0};
-  if (hipMalloc(&s.p, bytes) != hipSuccess) return nullptr;
-  s.cap = bytes;
-  slabs[n++] = s;
-  return s.p;
+    *e = Slab{st, nullptr, 0, 0};
+  }
+  e->used = ++tick;
+  if (e->cap < bytes) {
+    if (e->p) {
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(e->p);
+    }
+    e->p = nullptr; e->cap = 0;
+    if (hipMalloc(&e->p, bytes) != hipSuccess) return nullptr;
+    e->cap = bytes;
+  }
+  return e->p;
 }
 
 int wgrad_halo_tw(const WgradArgs& a) {
@@ -405,7 +419,7 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   const size_t lds = (size_t)KH * (128 * KH + NI * 10 * pitch) * 64 * sizeof(T) + 512 * nseg;     // NBUF = KH buffers of (KH dY halves + halo)
   (void)HP;
   auto kern = wgrad3x3_halo_kernel<T, TW, KH>;
-  static bool attr_done = false;
+  static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, KH == 1 ? 96 * 1024 : 160 * 1024);
     if (e != hipSuccess) return e;

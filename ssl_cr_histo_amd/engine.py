@@ -50,6 +50,9 @@ _ENGINE_SIGS = {
                                     C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sslcr_net_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sslcr_net_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "sslcr_net_debug_tap": (C.c_int, [C.c_void_p, C.c_int]),
+    "sslcr_net_debug_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.c_void_p]),
     "sslcr_net_optimizer_step": (C.c_int, [C.c_void_p, C.POINTER(L.OptDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                            C.c_void_p]),
     "sslcr_net_lookahead": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_float, C.c_void_p]),
@@ -161,6 +164,21 @@ class BoundNet:
         out = torch.empty_like(self.params[index])
         L.check(L.lib().sslcr_net_grad(self.handle, index, L.ptr(out), L.stream_ptr()))
         return out
+
+    def debug_tap(self, on):
+        """keep copies of every block's transient gradient tensors in backward (layer-wise parity test; see include/sslcr.h)."""
+        L.check(L.lib().sslcr_net_debug_tap(self.handle, int(bool(on))))
+
+    def debug_tensor(self, block, kind):
+        """-> (tensor in the engine's storage dtype, flags); kinds as in include/sslcr.h:sslcr_net_debug_tensor."""
+        dims, flags = (C.c_int * 4)(), C.c_int()
+        L.check(L.lib().sslcr_net_debug_tensor(self.handle, block, kind, None, 0, dims, C.byref(flags), L.stream_ptr()))
+        shape = [d for d in dims]
+        dt = torch.float32 if kind >= 11 or self.engine.dtype == 0 else torch.bfloat16
+        out = torch.empty(shape if kind < 11 else shape[:1], dtype=dt, device=self.engine.device)
+        L.check(L.lib().sslcr_net_debug_tensor(self.handle, block, kind, L.ptr(out), out.numel() * out.element_size(), dims,
+                                               C.byref(flags), L.stream_ptr()))
+        return out, flags.value
 
     def _note_buffers_changed(self):
         # the engine updated running stats / will update params through raw pointers: keep our signature in step so

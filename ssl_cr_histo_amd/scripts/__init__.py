@@ -18,7 +18,7 @@ SCRIPTS = {
     "eval_Kather_SSL_CR": {"train": "kather_cr_train", "validate": "kather_cr_validate", "teacher_refresh": "teacher_refresh"},
     "eval_BreastPathQ_SSL": {"train": "bpq_sup_train", "validate": "bpq_cr_validate", "teacher_refresh": "teacher_refresh"},
     "eval_Camelyon_SSL": {"train": "cam_sup_train", "validate": "cam_cr_validate", "teacher_refresh": "teacher_refresh"},
-    "eval_Kather_SSL": {"train": "kather_sup_train", "validate": "kather_sup_validate"},
+    "eval_Kather_SSL": {"train": "kather_sup_train", "validate": "kather_sup_validate", "teacher_refresh": "teacher_refresh"},
     "pretrain_BreastPathQ": {"train": "rsp_train", "validate": "rsp_validate", "teacher_refresh": "teacher_refresh"},
     "pretrain_Camelyon16": {"train": "rsp_train", "validate": "rsp_validate", "teacher_refresh": "teacher_refresh"},
     "pretrain_RSP": {"train": "rsp_train", "validate": "rsp_validate", "teacher_refresh": "teacher_refresh"},
@@ -31,7 +31,10 @@ class _ScriptFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def find_spec(self, fullname, path=None, target=None):
         pkg, _, name = fullname.rpartition(".")
         if pkg == __name__ and name in SCRIPTS:
-            return importlib.machinery.ModuleSpec(fullname, self)
+            # origin = this file: the synthesised modules have a __file__ / __spec__.origin for tracebacks, inspect and reload
+            spec = importlib.machinery.ModuleSpec(fullname, self, origin=__file__)
+            spec.has_location = True
+            return spec
         return None
 
     def create_module(self, spec):
@@ -47,6 +50,10 @@ class _ScriptFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 
 if not any(isinstance(f, _ScriptFinder) for f in sys.meta_path):
     sys.meta_path.append(_ScriptFinder())
+
+
+def __dir__():                   # pkgutil / dir() see the script modules although there is no file per script
+    return sorted(list(globals()) + list(SCRIPTS))
 
 
 def __getattr__(name):          # `from ssl_cr_histo_amd.scripts import test_Camelyon16`

@@ -216,9 +216,21 @@ def kather_cr_validate(args, model_student, classifier_student, val_loader, epoc
 
 
 # ------------------------------------------------------------------------------------------------ RSP pretraining
+def _plain_ce(criterion, where):
+    """the engine computes plain mean cross-entropy (what the reference's nn.CrossEntropyLoss() is): anything else -- class
+    weights, label smoothing, a non-default ignore_index or reduction -- must not be silently dropped."""
+    if criterion is None:
+        return
+    if not isinstance(criterion, torch.nn.CrossEntropyLoss):
+        raise NotImplementedError(f"{where}: the reference uses nn.CrossEntropyLoss")
+    if criterion.weight is not None or getattr(criterion, "label_smoothing", 0.0) != 0.0 or criterion.reduction != "mean" or \
+            criterion.ignore_index != -100:
+        raise NotImplementedError(f"{where}: only the default nn.CrossEntropyLoss() (no weight / label_smoothing / ignore_index, "
+                                  "reduction='mean') is implemented by the engine")
+
+
 def _rsp_epoch(args, model, classifier, loader, criterion, optimizer, epoch, train):
-    if criterion is not None and not isinstance(criterion, torch.nn.CrossEntropyLoss):
-        raise NotImplementedError("the reference trains RSP with nn.CrossEntropyLoss")
+    _plain_ce(criterion, "RSP pretraining (pretrain_BreastPathQ.py:56)")
     eng = get_engine(_device_of(model))
     model.train(train)
     classifier.train(train)
@@ -302,8 +314,7 @@ def bpq_sup_train(args, model, classifier, train_loader, criterion, optimizer, e
 
 def kather_sup_train(args, model, classifier, train_loader, criterion, optimizer, epoch):
     """eval_Kather_SSL.train (:32-99; the reference file does not parse as a whole, :243): student-only CE -> (loss, acc)."""
-    if criterion is not None and not isinstance(criterion, torch.nn.CrossEntropyLoss):
-        raise NotImplementedError("the reference fine-tunes Kather with nn.CrossEntropyLoss (eval_Kather_SSL.py:410)")
+    _plain_ce(criterion, "Kather fine-tuning (eval_Kather_SSL.py:410)")
     eng = get_engine(_device_of(model))
     model.train()
     classifier.train()
@@ -321,8 +332,7 @@ def kather_sup_train(args, model, classifier, train_loader, criterion, optimizer
 
 def kather_sup_validate(args, model, classifier, val_loader, criterion, epoch):
     """eval_Kather_SSL.validate (:102-151) -> (loss_avg, acc_avg): eval-mode forward + CE + accuracy."""
-    if criterion is not None and not isinstance(criterion, torch.nn.CrossEntropyLoss):
-        raise NotImplementedError("the reference validates Kather with nn.CrossEntropyLoss")
+    _plain_ce(criterion, "Kather validation (eval_Kather_SSL.py:102-151)")
     return kather_cr_validate(args, model, classifier, val_loader, epoch)
 
 

@@ -1,4 +1,5 @@
 """Shared helpers for the oracle- and engine-side golden comparisons."""
+import json
 import os
 from collections import OrderedDict
 
@@ -9,6 +10,37 @@ from oracle import cases as C
 from oracle import model as OM
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---------------------------------------------------------------- measured-error bounds for the reduced-precision modes
+# bf16 / fp8 engine modes cannot meet the north-star 1e-3; what they are held to is what they MEASURE on the MI355X: every
+# such assertion goes through held(key, err, ceiling), and tests/measured_errors.json records the worst value seen per key on
+# the GPU box.  The bound is 2 x that value (never below `floor`, never above the stated `ceiling`), so a regression that doubles
+# an error fails instead of hiding under a generous constant.  Refresh after a deliberate numerics change:
+#   SSLCR_RECORD_ERRORS=gpurun_out/errors.jsonl python -m pytest tests -m gpu ; python tools/update_measured.py gpurun_out/errors.jsonl
+MEASURED_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "measured_errors.json")
+try:
+    with open(MEASURED_PATH) as _f:
+        MEASURED = json.load(_f)
+except FileNotFoundError:
+    MEASURED = {}
+
+
+def bound_for(key, ceiling, floor=0.0):
+    m = MEASURED.get(key)
+    return ceiling if m is None else min(ceiling, max(2.0 * m, floor))
+
+
+def held(key, err, ceiling, floor=0.0, what=""):
+    """assert err <= min(ceiling, max(2 x measured[key], floor)); with SSLCR_RECORD_ERRORS=<file> also append the value."""
+    err = float(err)
+    rec = os.environ.get("SSLCR_RECORD_ERRORS")
+    if rec:
+        with open(rec, "a") as f:
+            f.write(json.dumps({"key": key, "err": err}) + "\n")
+    b = bound_for(key, ceiling, floor)
+    assert err <= b, f"{key}: {err:.4e} > bound {b:.4e} (measured {MEASURED.get(key)}, ceiling {ceiling}) {what}"
+    return err
 
 
 def load_golden(name):

@@ -18,7 +18,7 @@ from oracle import cases as C  # noqa: E402
 from oracle import model as OM  # noqa: E402
 from oracle import steps as S  # noqa: E402
 
-from _util import check_snapshot, load_golden, merged, oracle_state, rel_err  # noqa: E402
+from _util import check_snapshot, held, load_golden, merged, oracle_state, rel_err  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -58,8 +58,47 @@ def ns(**kw):
     return types.SimpleNamespace(print_freq=0, **kw)
 
 
-# tolerances: (return scalars, feats, post-step snapshot)
+# tolerances: (return scalars, feats, post-step snapshot).  fp32 engine mode carries the stated bounds.  The bf16 figures are
+# CEILINGS only: every bf16 assertion goes through near() -> _util.held(), i.e. 2 x the error measured on the MI355X for that
+# very quantity (tests/measured_errors.json holds the table), floored at 2e-3 so that rounding-order noise cannot trip it.
 TOLS = {"fp32": (1e-3, 1e-3, 5e-3), "bf16": (6e-2, 6e-2, 1e-1)}
+
+
+def near(key, dtype, err, tol32, ceil16, floor=2e-3):
+    if dtype == "fp32":
+        assert err <= tol32, (key, err, tol32)
+    else:
+        held(f"{key}/{dtype}", err, ceil16, floor)
+
+
+def relx(got, want):
+    return abs(float(got) - float(want)) / (abs(float(want)) + 1e-30)
+
+
+def grad_rows_check(name, dtype, names, grad_of, g, emu_key="grad_bf16emul_err"):
+    """every parameter gradient against the float64 run of the same iteration: L2 norm and one seeded +-1 projection.
+    fp32: max(3e-3, 3 x the reference's own fp32 error).  bf16: 2 x the measured error of THIS parameter (floor 1e-2 for the norm;
+    a single +-1 projection of an error vector e is ~N(0, |e|^2), so its floor is the parameter's measured norm-scale error:
+    3.5 sigma of the emulated bf16-storage error), never above the old 2 x / 3.5 x emulation + 0.05 rule."""
+    l2_ref, pr_ref, ref_err, emu = g[f"{name}/grad_l2_f64"], g[f"{name}/grad_probe_f64"], g[f"{name}/grad_ref32_err"], g[f"{name}/{emu_key}"]
+    rows, bad = [], []
+    for i, k in enumerate(names):
+        gr = grad_of(i).cpu().double().reshape(-1)
+        e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
+        e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
+        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}  "
+                    f"(reference fp32: {ref_err[i]:.2e}, bf16 emulation: {emu[i]:.2e})")
+        try:
+            if dtype == "fp32":
+                tol = max(3e-3, 3.0 * ref_err[i])
+                assert e_l2 <= tol and e_pr <= tol
+            else:
+                held(f"{name}/grad_l2/{i}/{dtype}", e_l2, 2.0 * emu[i] + 0.05, floor=1e-2)
+                held(f"{name}/grad_pr/{i}/{dtype}", e_pr, 3.5 * emu[i] + 0.05, floor=max(1e-2, 1.75 * emu[i]))
+        except AssertionError as ex:
+            bad.append(rows[-1] + f"   <- {ex}")
+    print(f"[{dtype}] {name} gradients vs the float64 run of the same iteration:\n" + "\n".join(rows))
+    assert not bad, "\n".join(bad)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -73,8 +112,7 @@ def test_backbone_forward_vs_reference_stages(mode, dtype):
     x = C.u8(5000, (2, 3, 64, 64)).to(DEV)
     feats = model(x)
     torch.cuda.synchronize()
-    tol = 1e-3 if dtype == "fp32" else 5e-2
-    assert rel_err(feats.cpu(), g[f"stages/{mode}/feats"]) < tol
+    near(f"stages/{mode}/feats", dtype, rel_err(feats.cpu(), g[f"stages/{mode}/feats"]), 1e-3, 5e-2)
     feats_f = model(x.float())                       # fp32 input path of the stem
     assert rel_err(feats_f.cpu(), feats.cpu()) < 1e-6
     if mode == "train":
@@ -90,7 +128,7 @@ def test_backbone_forward_vs_reference_stages(mode, dtype):
         sd2 = model2.state_dict()
         for k in ("model.bn1.running_mean", "model.bn1.running_var", "model.layer3.0.downsample.1.running_mean",
                   "model.layer4.1.bn2.running_var"):
-            assert rel_err(sd2[k].cpu(), g[f"stages/train/{k}"]) < (1e-4 if dtype == "fp32" else 2e-2), k
+            near(f"stages/train/{k}", dtype, rel_err(sd2[k].cpu(), g[f"stages/train/{k}"]), 1e-4, 2e-2)
         assert int(sd2["model.bn1.num_batches_tracked"]) == 3
 
 
@@ -110,13 +148,13 @@ def test_bpq_cr_epoch_vs_reference(name, dtype):
     ret = steps.bpq_cr_train(ns(lambda_u=c["lambda_u"]), mt, ms, ct, cs, C.labeled_batches(name), C.unlabeled_batches(name), opt, 1)
     ts, tf, tp = TOLS[dtype]
     for i in range(3):
-        assert abs(ret[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i]), (i, ret[i], g[f"{name}/ret"][i])
-    assert rel_err(ret[3].cpu(), g[f"{name}/feats"]) < tf
+        near(f"{name}/ret{i}", dtype, relx(ret[i], g[f"{name}/ret"][i]), ts, ts)
+    near(f"{name}/feats", dtype, rel_err(ret[3].cpu(), g[f"{name}/feats"]), tf, tf)
     assert torch.equal(ret[4].cpu(), torch.from_numpy(g[f"{name}/targets"]))
     if dtype == "fp32":
         check_snapshot(g, name, state_of(ms, cs), tp)
     val = steps.bpq_cr_validate(ns(), ms, cs, C.val_batches_reg(name), 1)
-    assert abs(val - g[f"{name}/val"][0]) <= (5e-3 if dtype == "fp32" else 1e-1) * abs(g[f"{name}/val"][0])
+    near(f"{name}/val", dtype, relx(val, g[f"{name}/val"][0]), 5e-3, 1e-1)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -153,12 +191,12 @@ def test_bpq_cr_full_size_step_vs_reference(dtype):
     ret = steps.bpq_cr_train(ns(lambda_u=c["lambda_u"]), mt, ms, ct, cs, C.labeled_batches(name), C.unlabeled_batches(name), opt, 1)
     ts, tf, tp = TOLS[dtype]
     for i in range(3):
-        assert abs(ret[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i]), (i, ret[i], g[f"{name}/ret"][i])
+        near(f"{name}/ret{i}", dtype, relx(ret[i], g[f"{name}/ret"][i]), ts, ts)
     f = ret[3].cpu().double()
     assert f.shape == (c["b"] * 3 + c["b"] * c["mu"], 768)
-    assert rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]) < tf
-    assert rel_err(f.sum(0), g[f"{name}/feats_colsum"]) < tf
-    assert rel_err(ret[3][:4].cpu(), g[f"{name}/feats_head"]) < tf
+    near(f"{name}/feats_rowl2", dtype, rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]), tf, tf)
+    near(f"{name}/feats_colsum", dtype, rel_err(f.sum(0), g[f"{name}/feats_colsum"]), tf, tf)
+    near(f"{name}/feats_head", dtype, rel_err(ret[3][:4].cpu(), g[f"{name}/feats_head"]), tf, tf)
     assert torch.equal(ret[4].cpu(), torch.from_numpy(g[f"{name}/targets"]))
     if dtype == "fp32":
         check_snapshot(g, name, state_of(ms, cs), tp)
@@ -175,23 +213,8 @@ def test_bpq_cr_full_size_step_vs_reference(dtype):
     names = [str(n) for n in g[f"{name}/grad_names"]]
     mine = [k for k, _ in list(ms.named_parameters()) + list(cs.named_parameters())]
     assert names == mine, "parameter order differs from the reference's named_parameters()"
-    l2_ref, pr_ref, ref_err = g[f"{name}/grad_l2_f64"], g[f"{name}/grad_probe_f64"], g[f"{name}/grad_ref32_err"]
-    rows, bad = [], []
-    for i, k in enumerate(names):
-        gr = st.grad(i).cpu().double().reshape(-1)
-        e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
-        e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
-        tol_l2 = tol_pr = max(3e-3, 3.0 * ref_err[i])
-        if dtype == "bf16":
-            # a single +-1 projection of an error vector e is ~N(0, |e|^2): 3.5 sigma for the projection, 2x for the norm
-            tol_l2 = 2.0 * g[f"{name}/grad_bf16emul_err"][i] + 0.05
-            tol_pr = 3.5 * g[f"{name}/grad_bf16emul_err"][i] + 0.05
-        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}  "
-                    f"(reference fp32: {ref_err[i]:.2e}, bound {tol_pr:.1e})")
-        if e_l2 > tol_l2 or e_pr > tol_pr:
-            bad.append(rows[-1])
-    print(f"[{dtype}] full-size gradients vs the float64 run of the same iteration:\n" + "\n".join(rows))
-    assert not bad, "\n".join(bad)
+    ref_err = g[f"{name}/grad_ref32_err"]
+    grad_rows_check(name, dtype, names, st.grad, g)
     assert abs(float(g[f"{name}/loss_f64"][0]) - g[f"{name}/ret"][0]) <= 1e-5 * g[f"{name}/ret"][0]     # one batch: average == the loss
     for key in g.files:
         if key.startswith(f"{name}/grad/"):
@@ -200,8 +223,8 @@ def test_bpq_cr_full_size_step_vs_reference(dtype):
             idx = names.index(k)
             got = st.grad(idx).cpu().double().reshape(want.shape)
             # full small tensors against the reference's fp32 .grad: two fp32 results, each ref_err from the exact one
-            bound = 3e-3 + 2.5 * ref_err[idx] if dtype == "fp32" else 2.0 * g[f"{name}/grad_bf16emul_err"][idx] + 0.05
-            assert rel_err(got, want) < bound, (k, rel_err(got, want), bound)
+            near(f"{name}/grad_full/{k}", dtype, rel_err(got, want), 3e-3 + 2.5 * ref_err[idx],
+                 2.0 * g[f"{name}/grad_bf16emul_err"][idx] + 0.05, floor=1e-2)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -223,16 +246,16 @@ def test_cam_cr_epoch_vs_reference(name, dtype):
                              C.unlabeled_batches(name, 2000), C.unlabeled_batches(name, 2100), opt, 1)
     ts, tf, tp = TOLS[dtype]
     for i in range(3):
-        assert abs(ret[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i]), (i, ret[i], g[f"{name}/ret"][i])
+        near(f"{name}/ret{i}", dtype, relx(ret[i], g[f"{name}/ret"][i]), ts, ts)
     if dtype == "fp32":
         assert ret[3] == g[f"{name}/ret"][3]
-    assert rel_err(ret[4].cpu(), g[f"{name}/feats"]) < tf
+    near(f"{name}/feats", dtype, rel_err(ret[4].cpu(), g[f"{name}/feats"]), tf, tf)
     assert torch.equal(ret[5].cpu(), torch.from_numpy(g[f"{name}/targets"]))
     if dtype == "fp32":
         check_snapshot(g, name, state_of(ms, cs), tp)
     torch.manual_seed(778)
     val = steps.cam_cr_validate(ns(), ms, cs, C.val_batches_cls(name, 4000, 1), C.val_batches_cls(name, 4100, 0), 1)
-    assert abs(val[0] - g[f"{name}/val"][0]) <= (2e-3 if dtype == "fp32" else 6e-2) * abs(g[f"{name}/val"][0])
+    near(f"{name}/val", dtype, relx(val[0], g[f"{name}/val"][0]), 2e-3, 6e-2)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -249,8 +272,7 @@ def test_cam_wsi_probability_map_vs_reference(dtype):
     assert pm.shape == want.shape and pm.dtype == np.float64
     assert np.array_equal(pm == 0, ~g[f"{name}/mask"])
     # probabilities in [0,1]: absolute tolerance.  fp32 mode 1e-3 of the logit scale; bf16 measured, not 1e-3
-    tol = 1e-3 if dtype == "fp32" else 6e-2
-    assert np.abs(pm - want).max() <= tol, np.abs(pm - want).max()
+    near(f"{name}/probability_map", dtype, np.abs(pm - want).max(), 1e-3, 6e-2)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -279,13 +301,12 @@ def test_cam_cr_full_size_step_vs_reference(dtype):
                              C.unlabeled_batches(name, 2000), C.unlabeled_batches(name, 2100), opt, 1)
     ts, tf, tp = TOLS[dtype]
     for i in range(3):
-        assert abs(ret[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i]), (i, ret[i], g[f"{name}/ret"][i])
+        near(f"{name}/ret{i}", dtype, relx(ret[i], g[f"{name}/ret"][i]), ts, ts)
     f = ret[4].cpu().double()
     assert list(f.shape) == list(g[f"{name}/feats_shape"])
-    tfe = tf if dtype == "fp32" else 0.2
-    assert rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]) < tfe
-    assert rel_err(f.sum(0), g[f"{name}/feats_colsum"]) < tfe
-    assert rel_err(ret[4][:4].cpu(), g[f"{name}/feats_head"]) < tfe
+    near(f"{name}/feats_rowl2", dtype, rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]), tf, 0.2)
+    near(f"{name}/feats_colsum", dtype, rel_err(f.sum(0), g[f"{name}/feats_colsum"]), tf, 0.2)
+    near(f"{name}/feats_head", dtype, rel_err(ret[4][:4].cpu(), g[f"{name}/feats_head"]), tf, 0.2)
     assert torch.equal(ret[5].cpu(), torch.from_numpy(g[f"{name}/targets"]))
     if dtype == "fp32":
         assert abs(ret[3] - g[f"{name}/ret"][3]) <= 1.0 / 192 + 1e-9            # accuracy (fraction) over 192 labeled images: at most one flip
@@ -296,21 +317,7 @@ def test_cam_cr_full_size_step_vs_reference(dtype):
     # against the FLOAT64 run of the same iteration (same shuffles), like the BreastPathQ full-size case: fp32 within
     # max(3e-3, 3 x the reference's own fp32 error); bf16 within 2 x (norm) / 3.5 x (one +-1 projection) the error that bf16
     # storage alone causes in the CPU emulation of this iteration (oracle/bf16_emul.py) + 0.05
-    l2_ref, pr_ref, ref_err, emu = g[f"{name}/grad_l2_f64"], g[f"{name}/grad_probe_f64"], g[f"{name}/grad_ref32_err"], g[f"{name}/grad_bf16emul_err"]
-    rows, bad = [], []
-    for i, k in enumerate(names):
-        gr = st.grad(i).cpu().double().reshape(-1)
-        e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
-        e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
-        tol_l2 = tol_pr = max(3e-3, 3.0 * ref_err[i])
-        if dtype == "bf16":
-            tol_l2, tol_pr = 2.0 * emu[i] + 0.05, 3.5 * emu[i] + 0.05
-        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}  "
-                    f"(reference fp32: {ref_err[i]:.2e}, bf16 emulation: {emu[i]:.2e})")
-        if e_l2 > tol_l2 or e_pr > tol_pr:
-            bad.append(rows[-1])
-    print(f"[{dtype}] Camelyon full-size gradients vs the float64 run of the same iteration:\n" + "\n".join(rows))
-    assert not bad, "\n".join(bad)
+    grad_rows_check(name, dtype, names, st.grad, g)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -330,12 +337,12 @@ def test_kather_cr_epoch_vs_reference(dtype):
                                 C.unlabeled_batches(name), opt, 1)
     ts, tf, tp = TOLS[dtype]
     for i in range(3):
-        assert abs(ret[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i]), (i, ret[i], g[f"{name}/ret"][i])
+        near(f"{name}/ret{i}", dtype, relx(ret[i], g[f"{name}/ret"][i]), ts, ts)
     if dtype == "fp32":
         assert ret[3] == g[f"{name}/ret"][3]
         check_snapshot(g, name, state_of(ms, cs), tp)
     val = steps.kather_cr_validate(ns(), ms, cs, C.val_batches_kather(name), 1)
-    assert abs(val[0] - g[f"{name}/val"][0]) <= (5e-3 if dtype == "fp32" else 1e-1) * g[f"{name}/val"][0]
+    near(f"{name}/val", dtype, relx(val[0], g[f"{name}/val"][0]), 5e-3, 1e-1)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -353,15 +360,15 @@ def test_rsp_epoch_and_lookahead_vs_reference(dtype):
     a = ns(tile_h=c["hw"], tile_w=c["hw"])
     ret = steps.rsp_train(a, model, cls, C.rsp_batches(name), torch.nn.CrossEntropyLoss(), opt, 1)
     ts, tf, tp = TOLS[dtype]
-    assert abs(ret[0] - g["rsp/ret"][0]) <= ts * g["rsp/ret"][0], (ret[0], g["rsp/ret"][0])
+    near("rsp/ret0", dtype, relx(ret[0], g["rsp/ret"][0]), ts, ts)
     # lr 0.01 SGD on BN statistics of 16 elements (layer4 at 64x64, B=4): bf16 noise is amplified by the 2nd step
-    assert rel_err(ret[2].cpu(), g["rsp/feats"]) < (tf if dtype == "fp32" else 0.2)
+    near("rsp/feats", dtype, rel_err(ret[2].cpu(), g["rsp/feats"]), tf, 0.2)
     assert torch.equal(ret[3].cpu(), torch.from_numpy(g["rsp/targets"]))
     if dtype == "fp32":
         assert ret[1] == g["rsp/ret"][1]
         check_snapshot(g, "rsp", state_of(model, cls), tp)
     val = steps.rsp_validate(a, model, cls, C.rsp_batches(name, 3500), torch.nn.CrossEntropyLoss(), 1)
-    assert abs(val[0] - g["rsp/val"][0]) <= (5e-3 if dtype == "fp32" else 1e-1) * g["rsp/val"][0]
+    near("rsp/val", dtype, relx(val[0], g["rsp/val"][0]), 5e-3, 1e-1)
     if dtype == "fp32":
         for _ in range(5):            # pretrain_BreastPathQ.py:293: Lookahead stepped with the last batch's stale gradients
             la.step()
@@ -387,13 +394,12 @@ def test_rsp_full_size_step_vs_reference(dtype):
     a = ns(tile_h=c["hw"], tile_w=c["hw"])
     ret = steps.rsp_train(a, model, cls, C.rsp_batches(name), torch.nn.CrossEntropyLoss(), opt, 1)
     ts, tf, tp = TOLS[dtype]
-    assert abs(ret[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0], (ret[0], g[f"{name}/ret"][0])
+    near(f"{name}/ret0", dtype, relx(ret[0], g[f"{name}/ret"][0]), ts, ts)
     f = ret[2].cpu().double()
     assert list(f.shape) == list(g[f"{name}/feats_shape"])
-    tfe = tf if dtype == "fp32" else 0.2
-    assert rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]) < tfe
-    assert rel_err(f.sum(0), g[f"{name}/feats_colsum"]) < tfe
-    assert rel_err(ret[2][:4].cpu(), g[f"{name}/feats_head"]) < tfe
+    near(f"{name}/feats_rowl2", dtype, rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]), tf, 0.2)
+    near(f"{name}/feats_colsum", dtype, rel_err(f.sum(0), g[f"{name}/feats_colsum"]), tf, 0.2)
+    near(f"{name}/feats_head", dtype, rel_err(ret[2][:4].cpu(), g[f"{name}/feats_head"]), tf, 0.2)
     assert torch.equal(ret[3].cpu(), torch.from_numpy(g[f"{name}/targets"]))
     if dtype == "fp32":
         assert abs(ret[1] - g[f"{name}/ret"][1]) <= 100.0 / c["b"] + 1e-9      # accuracy in percent: at most one flipped prediction
@@ -411,21 +417,7 @@ def test_rsp_full_size_step_vs_reference(dtype):
     assert names == mine
     # against the FLOAT64 run of the same iteration: fp32 within max(3e-3, 3 x the reference's own fp32 error); bf16 within
     # 2 x / 3.5 x the emulated bf16-storage error + 0.05 (norm / one +-1 projection) -- the rule of the SSL_CR full-size cases
-    l2_ref, pr_ref, ref_err, emu = g[f"{name}/grad_l2_f64"], g[f"{name}/grad_probe_f64"], g[f"{name}/grad_ref32_err"], g[f"{name}/grad_bf16emul_err"]
-    rows, bad = [], []
-    for i, k in enumerate(names):
-        gr = net_.grad(i).cpu().double().reshape(-1)
-        e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
-        e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
-        tol_l2 = tol_pr = max(3e-3, 3.0 * ref_err[i])
-        if dtype == "bf16":
-            tol_l2, tol_pr = 2.0 * emu[i] + 0.05, 3.5 * emu[i] + 0.05
-        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e}  projection err/|g| {e_pr:.2e}  "
-                    f"(reference fp32: {ref_err[i]:.2e}, bf16 emulation: {emu[i]:.2e})")
-        if e_l2 > tol_l2 or e_pr > tol_pr:
-            bad.append(rows[-1])
-    print(f"[{dtype}] RSP full-size gradients vs the float64 run of the same iteration:\n" + "\n".join(rows))
-    assert not bad, "\n".join(bad)
+    grad_rows_check(name, dtype, names, net_.grad, g)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -441,8 +433,8 @@ def test_supervised_epochs_vs_reference(dtype):
     torch.manual_seed(779)
     ret = steps.cam_sup_train(ns(image_size=c["hw"]), ms, cs, C.labeled_batches_cls(name, 1000, 1),
                               C.labeled_batches_cls(name, 1100, 0), opt, 1)
-    assert abs(ret[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0]
-    assert rel_err(ret[2].cpu(), g[f"{name}/feats"]) < tf
+    near(f"{name}/ret0", dtype, relx(ret[0], g[f"{name}/ret"][0]), ts, ts)
+    near(f"{name}/feats", dtype, rel_err(ret[2].cpu(), g[f"{name}/feats"]), tf, tf)
     if dtype == "fp32":
         check_snapshot(g, name, state_of(ms, cs), tp)
     name = "bpq_sup"
@@ -451,9 +443,9 @@ def test_supervised_epochs_vs_reference(dtype):
     ms, cs = build("finetune", "finetune", 1, False)
     opt = torch.optim.Adam(list(ms.parameters()) + list(cs.parameters()), lr=c["lr"], betas=(0.9, 0.999), weight_decay=c["wd"])
     ret = steps.bpq_sup_train(ns(image_size=c["hw"]), ms, cs, C.labeled_batches(name), torch.nn.MSELoss(), opt, 1)
-    assert abs(ret[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0]
+    near(f"{name}/ret0", dtype, relx(ret[0], g[f"{name}/ret"][0]), ts, ts)
     # Adam lr 1e-3 moves every weight by ~lr regardless of gradient size: bf16 gradient noise shows after step 1
-    assert rel_err(ret[1].cpu(), g[f"{name}/feats"]) < (tf if dtype == "fp32" else 0.2)
+    near(f"{name}/feats", dtype, rel_err(ret[1].cpu(), g[f"{name}/feats"]), tf, 0.2)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
@@ -487,10 +479,9 @@ def test_gradients_vs_oracle(kind, dtype):
         lt = OM.classifier_forward(pt, OM.finetune_forward(pt, bn_t, u_w.float(), False, True))
     g32, logits, loss = B.ssl_cr_grads(kind, ps, x.float(), y, u_s.float(), lt, lam, emulate=False)
     got = r["losses"].cpu()
-    tl = 1e-3 if dtype == "fp32" else 6e-2
-    assert abs(got[0] - loss) <= tl * abs(loss), (got, loss)
-    assert rel_err(r["logits"].cpu(), logits) < tl
-    assert rel_err(r["logits_t"].cpu(), lt) < tl
+    near(f"grads_vs_oracle/{kind}/loss", dtype, relx(got[0], loss), 1e-3, 6e-2)
+    near(f"grads_vs_oracle/{kind}/logits", dtype, rel_err(r["logits"].cpu(), logits), 1e-3, 6e-2)
+    near(f"grads_vs_oracle/{kind}/logits_t", dtype, rel_err(r["logits_t"].cpu(), lt), 1e-3, 6e-2)
     if dtype == "bf16":
         g16, _, _ = B.ssl_cr_grads(kind, ps, x.float(), y, u_s.float(), lt, lam, emulate=True)
     rows, bad = [], []
@@ -498,9 +489,11 @@ def test_gradients_vs_oracle(kind, dtype):
         ref = g32[k].double()
         e = float((st.grad(i).cpu().double() - ref).norm() / (ref.norm() + 1e-30))
         bound = 3e-3 if dtype == "fp32" else 2.0 * float((g16[k].double() - ref).norm() / (ref.norm() + 1e-30)) + 0.05
-        rows.append(f"   {i:2d} {k:40s} err {e:.3e}  bound {bound:.3e}")
-        if e > bound:
-            bad.append(rows[-1])
+        rows.append(f"   {i:2d} {k:40s} err {e:.3e}  ceiling {bound:.3e}")
+        try:
+            near(f"grads_vs_oracle/{kind}/grad/{i}", dtype, e, bound, bound, floor=1e-2)
+        except AssertionError as ex:
+            bad.append(rows[-1] + f"   <- {ex}")
     print(f"[{dtype}/{kind}] relative L2 gradient error per parameter:\n" + "\n".join(rows))
     assert not bad, "\n".join(bad)
 

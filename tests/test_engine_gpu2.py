@@ -14,22 +14,8 @@ from oracle import cases as C  # noqa: E402
 from oracle import model as OM  # noqa: E402
 from oracle import steps as S  # noqa: E402
 
-from _util import check_snapshot, load_golden, merged, oracle_state, rebuild_ckpt, rel_err  # noqa: E402
-from test_engine_gpu import DEV, TOLS, _engine, build, freeze, ns, state_of  # noqa: E402
-
-
-def _grad_table(tag, st, names, l2_ref, pr_ref, tol_fn):
-    rows, bad = [], []
-    for i, k in enumerate(names):
-        gr = st.grad(i).cpu().double().reshape(-1)
-        e_l2 = abs(float(gr.norm()) - l2_ref[i]) / (l2_ref[i] + 1e-30)
-        e_pr = abs(float((gr * C.grad_probe(i, gr.numel())).sum()) - pr_ref[i]) / (l2_ref[i] + 1e-30)
-        tol_l2, tol_pr = tol_fn(i)
-        rows.append(f"   {i:2d} {k:40s} |g| {l2_ref[i]:.3e}  norm err {e_l2:.2e} (<= {tol_l2:.1e})  projection err/|g| {e_pr:.2e} (<= {tol_pr:.1e})")
-        if e_l2 > tol_l2 or e_pr > tol_pr:
-            bad.append(rows[-1])
-    print(tag + "\n" + "\n".join(rows))
-    assert not bad, "\n".join(bad)
+from _util import check_snapshot, held, load_golden, merged, oracle_state, rebuild_ckpt, rel_err  # noqa: E402
+from test_engine_gpu import DEV, TOLS, _engine, build, freeze, grad_rows_check, near, ns, relx, state_of  # noqa: E402
 
 
 # ------------------------------------------------------------------------------------------------ config 1: Kather supervised
@@ -47,12 +33,12 @@ def test_kather_supervised_epoch_vs_reference(dtype):
     crit = torch.nn.CrossEntropyLoss()
     ret = steps.kather_sup_train(ns(image_size=c["hw"]), ms, cs, C.sup_batches_kather(name), crit, opt, 1)
     ts, tf, tp = TOLS[dtype]
-    assert abs(ret[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0], (ret[0], g[f"{name}/ret"][0])
+    near(f"{name}/ret0", dtype, relx(ret[0], g[f"{name}/ret"][0]), ts, ts)
     if dtype == "fp32":
         assert ret[1] == g[f"{name}/ret"][1]
         check_snapshot(g, name, state_of(ms, cs), tp)
     val = steps.kather_sup_validate(ns(), ms, cs, C.val_batches_kather(name), crit, 1)
-    assert abs(val[0] - g[f"{name}/val"][0]) <= (5e-3 if dtype == "fp32" else 1e-1) * g[f"{name}/val"][0]
+    near(f"{name}/val", dtype, relx(val[0], g[f"{name}/val"][0]), 5e-3, 1e-1)
     if dtype == "fp32":
         assert val[1] == g[f"{name}/val"][1]
 
@@ -73,24 +59,16 @@ def test_kather_config1_full_size_step_vs_reference(dtype):
     crit = torch.nn.CrossEntropyLoss()
     ret = steps.kather_sup_train(ns(image_size=c["hw"]), ms, cs, C.sup_batches_kather(name), crit, opt, 1)
     ts, tf, tp = TOLS[dtype]
-    assert abs(ret[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0], (ret[0], g[f"{name}/ret"][0])
+    near(f"{name}/ret0", dtype, relx(ret[0], g[f"{name}/ret"][0]), ts, ts)
     assert abs(ret[1] - g[f"{name}/ret"][1]) <= (1.0 if dtype == "fp32" else 3.0) / 96 + 1e-9
     if dtype == "fp32":
         check_snapshot(g, name, state_of(ms, cs), tp)
     st = eng.bind(ms, cs)                      # the epoch function's binding: gradients of its (only) backward
     names = [str(n) for n in g[f"{name}/grad_names"]]
     assert names == [k for k, _ in list(ms.named_parameters()) + list(cs.named_parameters())]
-    ref_err, emu = g[f"{name}/grad_ref32_err"], g[f"{name}/grad_bf16emul_err"]
-
-    def tol(i):
-        if dtype == "fp32":
-            t = max(3e-3, 3.0 * ref_err[i])
-            return t, t
-        return 2.0 * emu[i] + 0.05, 3.5 * emu[i] + 0.05
-    _grad_table(f"[{dtype}] config-1 gradients vs the float64 run of the same iteration:", st, names, g[f"{name}/grad_l2_f64"],
-                g[f"{name}/grad_probe_f64"], tol)
+    grad_rows_check(name, dtype, names, st.grad, g)
     val = steps.kather_sup_validate(ns(), ms, cs, C.val_batches_kather(name), crit, 1)
-    assert abs(val[0] - g[f"{name}/val"][0]) <= (5e-3 if dtype == "fp32" else 1e-1) * g[f"{name}/val"][0]
+    near(f"{name}/val", dtype, relx(val[0], g[f"{name}/val"][0]), 5e-3, 1e-1)
 
 
 # ------------------------------------------------------------------------------------------------ a11: EMA teacher
@@ -174,7 +152,7 @@ def test_checkpoint_ssl_cr_resume_continues_like_the_reference(source, dtype, tm
         mt, ct, ms, cs, opt = fresh()
         r1 = steps.bpq_cr_train(a, mt, ms, ct, cs, C.labeled_batches(name), C.unlabeled_batches(name), opt, 1)
         for i in range(3):
-            assert abs(r1[i] - g[f"{name}/ret"][i]) <= ts * abs(g[f"{name}/ret"][i])
+            near(f"{name}/ret{i}", dtype, relx(r1[i], g[f"{name}/ret"][i]), ts, ts)
         mt, ct = copy.deepcopy(ms), copy.deepcopy(cs)                                   # :515-516
         CK.save_ssl_cr(f, None, ms, mt, ct, cs, opt, 1, r1[0], r1[1], r1[2])
     mt, ct, ms, cs, opt = fresh()
@@ -182,8 +160,8 @@ def test_checkpoint_ssl_cr_resume_continues_like_the_reference(source, dtype, tm
     assert start == 2
     r2 = steps.bpq_cr_train(a, mt, ms, ct, cs, C.labeled_batches(name, 1200), C.unlabeled_batches(name, 2200), opt, start)
     for i in range(3):
-        assert abs(r2[i] - g[f"{name}/ret2"][i]) <= ts * abs(g[f"{name}/ret2"][i]), (i, r2[i], g[f"{name}/ret2"][i])
-    assert rel_err(r2[3].cpu(), g[f"{name}/feats2"]) < tf
+        near(f"{name}/{source}/ret2_{i}", dtype, relx(r2[i], g[f"{name}/ret2"][i]), ts, ts)
+    near(f"{name}/{source}/feats2", dtype, rel_err(r2[3].cpu(), g[f"{name}/feats2"]), tf, tf)
     if dtype == "fp32":
         check_snapshot(g, name + "/e2", state_of(ms, cs), tp)
 
@@ -211,8 +189,8 @@ def test_checkpoint_finetune_resume_and_ssl_cr_start(dtype, tmp_path):
     torch.manual_seed(782)
     r2 = steps.cam_sup_train(ns(image_size=c["hw"]), msw, csw, C.labeled_batches_cls(name, 1200, 1), C.labeled_batches_cls(name, 1300, 0),
                              opt, start)
-    assert abs(r2[0] - g[f"{name}/ret2"][0]) <= ts * g[f"{name}/ret2"][0]
-    assert rel_err(r2[2].cpu(), g[f"{name}/feats2"]) < tf
+    near(f"{name}/ret2_0", dtype, relx(r2[0], g[f"{name}/ret2"][0]), ts, ts)
+    near(f"{name}/feats2", dtype, rel_err(r2[2].cpu(), g[f"{name}/feats2"]), tf, tf)
     if dtype == "fp32":
         assert r2[1] == g[f"{name}/ret2"][1]
         check_snapshot(g, name + "/e2", state_of(ms, cs), tp)
@@ -246,7 +224,7 @@ def test_checkpoint_pretrain_resume_continues_like_the_reference(dtype, tmp_path
     crit = torch.nn.CrossEntropyLoss()
     r1 = steps.rsp_train(a, model, cls, C.rsp_batches(name), crit, opt, 1)
     sched.step()                                                                   # pretrain_BreastPathQ.py:293
-    assert abs(r1[0] - g[f"{name}/ret"][0]) <= ts * g[f"{name}/ret"][0]
+    near(f"{name}/ret0", dtype, relx(r1[0], g[f"{name}/ret"][0]), ts, ts)
     if dtype == "fp32":
         check_snapshot(g, name + "/e1", state_of(model, cls), 2e-2)
     f = str(tmp_path / "model_1.pt")
@@ -267,7 +245,7 @@ def test_checkpoint_pretrain_resume_continues_like_the_reference(dtype, tmp_path
         assert e <= max(2e-3, 2.0 * ref_err), (e, ref_err)
         check_snapshot(g, name + "/e2", state_of(model, cls), 2e-2)
     else:
-        assert abs(r2[0] - g[f"{name}/ret2"][0]) <= 0.15 * g[f"{name}/ret2"][0]
+        held(f"{name}/ret2/{dtype}", relx(r2[0], g[f"{name}/ret2"][0]), 0.15, floor=2e-3)
 
 
 # ------------------------------------------------------------------------------------------------ trajectories (bf16 fidelity)
@@ -324,10 +302,13 @@ def test_trajectory_vs_reference(name, dtype):
         # 1e-2 after 12 iterations, 2.2e-2 after 24)
         check_snapshot(g, name, state_of(ms, cs), 5e-2)
     else:
-        assert max(dev) <= 3e-2, dev
+        # per iteration: 2 x the deviation measured for THAT iteration (tests/measured_errors.json), floor 2e-3, ceiling 3e-2
+        for it, d_ in enumerate(dev):
+            held(f"{name}/iter{it:02d}/{dtype}", d_, 3e-2, floor=2e-3)
         mid, tail = float(np.mean(dev[8:16])), float(np.mean(dev[-8:]))
         assert tail <= 1.3 * mid + 2e-3, (mid, tail, dev)
-        assert max(vdev) <= 5e-2, vdev
+        for j, d_ in enumerate(vdev):
+            held(f"{name}/val{j}/{dtype}", d_, 5e-2, floor=2e-3)
 
 
 # ------------------------------------------------------------------------------------------------ e: virtual ranks on one GPU
@@ -424,9 +405,13 @@ def test_virtual_ranks_equal_the_single_device_step(world, workload, dtype):
         # flat across conv1 .. layer4, losses equal to 1e-5); worlds 2 and 4 hold the arithmetic to 2e-5
         tg, tsn = 3e-3, 1e-3
     total = sum(o["losses"] for o in ranks)
-    assert torch.allclose(total[:3], single["losses"][:3], rtol=tl, atol=1e-7), (total, single["losses"])
+    if dtype == "fp32":
+        assert torch.allclose(total[:3], single["losses"][:3], rtol=tl, atol=1e-7), (total, single["losses"])
+    else:
+        held(f"vranks/{workload}/w{world}/losses/{dtype}", float(((total[:3] - single["losses"][:3]).abs() / (single["losses"][:3].abs() + 1e-7)).max()),
+             tl, floor=1e-3)
     assert abs(float(total[3] - single["losses"][3])) <= (0 if dtype == "fp32" else 2)           # correct-prediction counts add up
-    worst = 0.0
+    worst = worst_state = 0.0
     prof = [float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(ranks[0]["grads"], single["grads"])]
     print(f"[{dtype}] {workload} world {world}: losses {total.tolist()} vs {single['losses'].tolist()}\n   rank-0 gradient deviation by parameter: " +
           " ".join(f"{e:.1e}" for e in prof))
@@ -434,12 +419,18 @@ def test_virtual_ranks_equal_the_single_device_step(world, workload, dtype):
         for i, (a, b) in enumerate(zip(o["grads"], single["grads"])):
             e = float((a - b).norm() / (b.norm() + 1e-30))
             worst = max(worst, e)
-            assert e <= (tg if dtype == "fp32" else 0.6), (r, i, e)
+            assert e <= tg, (r, i, e)
         for k, v in single["state"].items():
             if "num_batches" in k:
                 assert int(o["state"][k]) == int(v), k
             else:
-                assert float((o["state"][k].double() - v.double()).norm() / (v.double().norm() + 1e-30)) <= tsn, (r, k)
+                es = float((o["state"][k].double() - v.double()).norm() / (v.double().norm() + 1e-30))
+                worst_state = max(worst_state, es)
+                assert es <= tsn, (r, k)
+    if dtype != "fp32":
+        # bf16: 2 x the measured worst per-parameter deviation (the ceilings 0.6 / 0.1 above only catch garbage)
+        held(f"vranks/{workload}/w{world}/grad_worst/{dtype}", worst, tg, floor=5e-2)
+        held(f"vranks/{workload}/w{world}/state_worst/{dtype}", worst_state, tsn, floor=5e-3)
     print(f"[{dtype}] {workload} world {world}: worst per-parameter gradient deviation from the single-device step {worst:.2e}")
     for e in engines:
         del e

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 from oracle import cases as C  # noqa: E402
 from oracle import kernels_ref as R  # noqa: E402
 
-from _util import load_golden, rel_err  # noqa: E402
+from _util import held, load_golden, rel_err  # noqa: E402
 from test_kernels_gpu import DEV, close, rnd  # noqa: E402
 
 FP8_CASES = [(2, 16, 16, 128, 128), (3, 32, 32, 128, 128), (2, 16, 16, 256, 256), (8, 8, 8, 512, 512), (4, 8, 8, 256, 128),
@@ -142,8 +142,10 @@ def test_fp8_camelyon_full_size_step_vs_reference():
     e_row = rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"])
     print(f"[fp8] Camelyon full-size step vs the reference: loss deviations {dev}, accuracy {ret[3]} vs {g[f'{name}/ret'][3]}, "
           f"feature row-norm error {e_row:.3e}")
-    assert max(dev) <= 6e-2, dev
-    assert e_row <= 0.25
+    # 2 x the deviations measured on the MI355X (tests/measured_errors.json), ceilings 6e-2 / 0.25
+    for i, d_ in enumerate(dev):
+        held(f"{name}/ret{i}/fp8", d_, 6e-2, floor=2e-3)
+    held(f"{name}/feats_rowl2/fp8", e_row, 0.25, floor=2e-3)
     assert torch.equal(ret[5].cpu(), torch.from_numpy(g[f"{name}/targets"]))
 
 
@@ -186,6 +188,11 @@ def test_fp8_config5_per_gpu_shape_vs_parity_engine():
     flips = int(((bq["logits_t"].argmax(1)) != (a["logits_t"].argmax(1))).sum())
     print(f"[fp8 vs fp32 engine, student {nx + nu} / teacher {nu}] loss deviations {dl}; logits rel L2 {e_log:.3e} (teacher {e_logt:.3e}); "
           f"pseudo-label flips {flips}/{nu}; classifier gradient rel L2 {e_g:.3e}, fc.0 gradient {e_fc:.3e}")
-    assert max(dl) <= 6e-2, dl
-    assert e_log <= 0.3 and e_logt <= 0.3
-    assert e_g <= 0.5
+    # 2 x the deviations measured on the MI355X (tests/measured_errors.json); the constants are ceilings
+    for i, d_ in enumerate(dl):
+        held(f"config5/loss{i}/fp8_vs_fp32", d_, 6e-2, floor=1e-3)
+    held("config5/logits/fp8_vs_fp32", e_log, 0.3, floor=1e-2)
+    held("config5/logits_t/fp8_vs_fp32", e_logt, 0.3, floor=1e-2)
+    held("config5/grad_classifier/fp8_vs_fp32", e_g, 0.5, floor=1e-2)
+    held("config5/grad_fc0/fp8_vs_fp32", e_fc, 0.5, floor=1e-2)
+    assert flips <= max(2, nu // 200), flips

@@ -98,6 +98,30 @@ def test_script_modules_expose_reference_names():
         "unlabeled_train_loader", "optimizer", "epoch"]
     assert list(inspect.signature(steps.rsp_train).parameters) == ["args", "model", "classifier", "train_loader", "criterion",
                                                                    "optimizer", "epoch"]
+    # the synthesised modules carry a location (tracebacks, inspect), survive a reload without a second finder, and are listed
+    import sys
+    m = importlib.import_module("ssl_cr_histo_amd.scripts.eval_Kather_SSL")
+    assert m.__spec__.origin == scripts.__file__ and m.__file__ == scripts.__file__ and callable(m.teacher_refresh)
+    n_finders = len(sys.meta_path)
+    assert importlib.reload(m).train is steps.kather_sup_train and len(sys.meta_path) == n_finders
+    assert "eval_Kather_SSL" in dir(scripts)
+
+
+def test_only_the_default_cross_entropy_criterion_is_accepted():
+    """the reference calls criterion(output, target) with nn.CrossEntropyLoss(); the engine computes plain mean CE, so a criterion
+    that carries class weights, label smoothing, a non-default ignore_index or reduction must raise instead of being ignored."""
+    import pytest
+    from ssl_cr_histo_amd import steps
+    steps._plain_ce(None, "x")
+    steps._plain_ce(torch.nn.CrossEntropyLoss(), "x")
+    for bad in (torch.nn.CrossEntropyLoss(weight=torch.ones(6)), torch.nn.CrossEntropyLoss(label_smoothing=0.1),
+                torch.nn.CrossEntropyLoss(reduction="sum"), torch.nn.CrossEntropyLoss(ignore_index=3), torch.nn.MSELoss()):
+        with pytest.raises(NotImplementedError):
+            steps._plain_ce(bad, "x")
+        with pytest.raises(NotImplementedError):
+            steps.kather_sup_validate(None, None, None, [], bad, 1)
+        with pytest.raises(NotImplementedError):
+            steps.rsp_validate(None, None, None, [], bad, 1)
 
 
 def test_weak_augment_params_follow_the_reference_draw_order():
