@@ -282,6 +282,10 @@ int sslcr_comm_init(sslcr_ctx* ctx, const void* id256, int rank, int world);
 /* what the communicator itself reports (ncclCommUserRank / ncclCommCount when RCCL is in use): rank, world, transport
  * (0 none, 1 RCCL, 2 virtual ranks) -- bench.py prints it as ranks_seen. */
 int sslcr_comm_info(sslcr_ctx* ctx, int* rank, int* world, int* transport);
+/* in-place SUM of `n` floats over the ranks of ctx's communicator (RCCL or virtual) on `stream`; nothing happens without one.
+ * The logging reduction of the step functions: per-rank loss shares -> global values, once per print_freq / epoch end (the
+ * reference's meters, eval_BreastPathQ_SSL_CR.py:103-110, read .item() of losses nn.DataParallel had already gathered). */
+int sslcr_comm_all_reduce_f32(sslcr_ctx* ctx, float* buf, size_t n, void* stream);
 /* "Virtual ranks" (test infrastructure for single-GPU boxes; RCCL refuses two ranks on one device): `world` contexts of ONE
  * process on ONE device, one host thread and one stream each, exchange through a sslcr_vcomm instead of RCCL.  Every sharded
  * code path of the engine -- synced BatchNorm sums forward and backward, global-count loss scaling, bucketed gradient sums on

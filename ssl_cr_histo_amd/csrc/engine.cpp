@@ -1389,6 +1389,12 @@ int sslcr_comm_info(sslcr_ctx* c, int* rank, int* world, int* transport) {
   return 0;
 }
 
+int sslcr_comm_all_reduce_f32(sslcr_ctx* c, float* buf, size_t n, void* stream) {
+  if (!c || (!buf && n)) return fail("sslcr_comm_all_reduce_f32: invalid argument");
+  if (!sharded(c) || n == 0) return 0;
+  return all_reduce(c, 0, buf, n, false, (hipStream_t)stream);
+}
+
 int sslcr_vcomm_create(sslcr_vcomm** out, int world) {
   if (!out || world < 1 || world > VW_MAX) return fail("sslcr_vcomm_create: world must be 1..%d", VW_MAX);
   sslcr_vcomm* v = new sslcr_vcomm();

@@ -1,6 +1,6 @@
 """One process per GPU: torch.distributed (backend "nccl" == RCCL on ROCm, or gloo on CPU for the tests) is used only
-to bootstrap -- rank/world discovery, broadcasting the RCCL unique id of the engine's own communicator, and logging
-all-reduces.  The data path collectives (gradient buckets, BatchNorm sums) are issued by the engine itself.
+to bootstrap -- rank/world discovery and broadcasting the RCCL unique id of the engine's own communicator.  Every collective after
+that (gradient buckets, BatchNorm sums, the loss meters' one all-reduce per print_freq) is issued by the engine itself.
 
 Sharding: pure data parallel; rank r takes labeled rows [r*b/G, (r+1)*b/G) and unlabeled rows
 [r*mu*b/G, ...) of the global batch; every loss is scaled by the GLOBAL count so the all-reduced SUM of the per-rank
@@ -56,12 +56,3 @@ def attach_engine(engine):
     if world > 1:
         engine.init_comm(rank, world, broadcast_bytes)
     return engine
-
-
-def global_mean_of_scaled(local_value):
-    """per-rank losses are already scaled by 1/global-count: the global mean is their SUM."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return local_value
-    t = local_value.clone() if torch.is_tensor(local_value) else torch.tensor(float(local_value))
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t

@@ -36,6 +36,7 @@ _ENGINE_SIGS = {
     "sslcr_comm_unique_id": (C.c_int, [C.c_void_p]),
     "sslcr_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "sslcr_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sslcr_comm_all_reduce_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sslcr_vcomm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "sslcr_vcomm_destroy": (C.c_int, [C.c_void_p]),
     "sslcr_comm_init_virtual": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -309,11 +310,15 @@ class Engine:
         off by default -- see include/sslcr.h)."""
         L.check(L.lib().sslcr_set_wgrad_stream(self.handle, int(bool(on))))
 
-    def _reduce_losses(self, losses):
-        """logging only: each rank's (loss, loss_x, loss_u) is already scaled by 1/global-count and #correct is a count,
-        so the SUM over ranks is the global value (the data-path collectives are issued by the engine itself)."""
-        if self.world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.all_reduce(losses)
+    def all_reduce_sum(self, t):
+        """in-place SUM of a contiguous fp32 device tensor over the ranks of the engine's own communicator (RCCL or virtual), on
+        the current stream; identity on one rank.  Logging path only (steps._Meters at print_freq / epoch end): the data-path
+        collectives -- gradient buckets, BatchNorm sums -- are issued inside the step by the engine itself."""
+        if self.world > 1:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise L.SslcrError("all_reduce_sum: contiguous fp32 tensor on the engine's device expected")
+            L.check(L.lib().sslcr_comm_all_reduce_f32(self.handle, L.ptr(t), t.numel(), L.stream_ptr()))
+        return t
 
     # ------------------------------------------------------------------ measurement
     def profile(self, enable):
@@ -367,7 +372,8 @@ class Engine:
     def step_ssl_cr(self, teacher, student, kind, x, y, u_w, u_s, lambda_u, backward=True, nx_global=None, nu_global=None):
         """one consistency-training iteration (eval_BreastPathQ_SSL_CR.py:65-100 / eval_Camelyon_SSL_CR.py:94-121).
         x [nx,3,H,W], u_w/u_s [nu,3,H,W] uint8|fp32; y [nx] fp32 (kind 'mse') or int64 (kind 'ce').
-        -> dict(losses [4] device tensor: loss, loss_x, loss_u, #correct ; feats ; logits ; logits_t)."""
+        -> dict(losses [4] device tensor: loss, loss_x, loss_u, #correct ; feats ; logits ; logits_t).  With more than one rank the
+        losses are this rank's share (scaled by 1/global-count; the SUM over ranks is the global value) -- no collective per step."""
         teacher.sync()
         student.sync()
         x, u_w, u_s = self.as_input(x), self.as_input(u_w), self.as_input(u_s)
@@ -392,7 +398,6 @@ class Engine:
                       int(nx_global or nx * self.world), int(nu_global or nu * self.world), feats.data_ptr(),
                       logits.data_ptr(), logits_t.data_ptr(), losses.data_ptr(), int(backward), u_s.data_ptr())
         L.check(L.lib().sslcr_step_ssl_cr(teacher.handle, student.handle, C.byref(d), L.stream_ptr()))
-        self._reduce_losses(losses)
         student._live_inputs = (x, u_s, u_w, tf, ti)
         student._note_buffers_changed()
         return dict(losses=losses, feats=feats, logits=logits, logits_t=logits_t)
@@ -416,7 +421,6 @@ class Engine:
                     None if ti is None else ti.data_ptr(), int(n_global or n * self.world), feats.data_ptr(),
                     logits.data_ptr(), losses.data_ptr(), int(train), int(backward and train))
         L.check(L.lib().sslcr_step_supervised(net.handle, C.byref(d), L.stream_ptr()))
-        self._reduce_losses(losses)
         net._live_inputs = (xs, tf, ti)
         if train:
             net._note_buffers_changed()

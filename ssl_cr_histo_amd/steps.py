@@ -22,31 +22,42 @@ from .util import AverageMeter
 
 
 class _Meters:
-    """AverageMeter semantics (util.py:26-46) fed from device scalars without a sync per step."""
+    """AverageMeter semantics (util.py:26-46) fed from device scalars without a sync per step.
 
-    def __init__(self, names):
+    Sharded runs (one process per GPU): a step's losses are THIS rank's share -- already scaled by 1/global-count, so the SUM
+    over ranks is the global value -- and stay local until somebody looks: meters() issues ONE all-reduce of all rows gathered so
+    far ("one small all-reduce per print_freq"), on the engine's own communicator, and only then syncs to the
+    host.  `reduce` is that in-place SUM over ranks (None on one rank), `world` scales the meter weights to global counts."""
+
+    def __init__(self, names, reduce=None, world=1):
         self.names = names
         self.rows, self.weights = [], []
+        self.reduce, self.world = reduce, world
+        self.done = []                      # rows already reduced and fetched: python lists
 
     def add(self, losses, n):
-        # sharded runs: `losses` are already all-reduced global values, so the meter weight is the global count
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            n = n * torch.distributed.get_world_size()
         self.rows.append(losses)
-        self.weights.append(n)
+        self.weights.append(n * self.world)
 
     def meters(self, acc_denoms=None):
         out = {k: AverageMeter() for k in self.names}
-        if not self.rows:
-            return out
-        vals = torch.stack(self.rows).cpu().tolist()              # the single device->host sync
-        for r, n in zip(vals, self.weights):
+        if self.rows:
+            vals = torch.stack(self.rows)
+            if self.reduce is not None:
+                self.reduce(vals)                                  # the one collective per print / epoch boundary
+            self.done += vals.cpu().tolist()                       # the single device->host sync
+            self.rows = []
+        for r, n in zip(self.done, self.weights):
             for k in self.names:
                 if k == "acc":
                     out[k].update(r[3] / n, n)
                 else:
                     out[k].update(r[{"loss": 0, "loss_x": 1, "loss_u": 2}[k]], n)
         return out
+
+
+def _meters(eng, names):
+    return _Meters(names, eng.all_reduce_sum if eng.world > 1 else None, eng.world)
 
 
 def _device_of(model):
@@ -78,7 +89,7 @@ def bpq_cr_train(args, model_teacher, model_student, classifier_teacher, classif
     for m in (model_student, classifier_student):
         m.train()
     te, st = eng.bind(model_teacher, classifier_teacher), eng.bind(model_student, classifier_student)
-    meters = _Meters(["loss", "loss_x", "loss_u"])
+    meters = _meters(eng, ["loss", "loss_x", "loss_u"])
     feats, targets = [], []
     t0 = time.time()
     for batch_idx, (data_x, data_u) in enumerate(zip(labeled_train_loader, unlabeled_train_loader)):
@@ -102,7 +113,7 @@ def bpq_cr_validate(args, model_student, classifier_student, val_loader, epoch):
     model_student.eval()
     classifier_student.eval()
     st = eng.bind(model_student, classifier_student)
-    meters = _Meters(["loss"])
+    meters = _meters(eng, ["loss"])
     t0 = time.time()
     for batch_idx, (input, target) in enumerate(val_loader):
         r = eng.step_supervised(st, "mse", [input], target.float().reshape(-1), train=False)
@@ -125,7 +136,7 @@ def cam_cr_train(args, model_teacher, model_student, classifier_teacher, classif
     for m in (model_student, classifier_student):
         m.train()
     te, st = eng.bind(model_teacher, classifier_teacher), eng.bind(model_student, classifier_student)
-    meters = _Meters(["loss", "loss_x", "loss_u", "acc"])
+    meters = _meters(eng, ["loss", "loss_x", "loss_u", "acc"])
     feats, targets = [], []
     t0 = time.time()
     S = args.image_size
@@ -160,7 +171,7 @@ def cam_cr_validate(args, model_student, classifier_student, val_tumor_loader, v
     model_student.eval()
     classifier_student.eval()
     st = eng.bind(model_student, classifier_student)
-    meters = _Meters(["loss", "acc"])
+    meters = _meters(eng, ["loss", "acc"])
     t0 = time.time()
     for batch_idx, (data_tumor, data_normal) in enumerate(zip(val_tumor_loader, val_normal_loader)):
         t_x, t_y = data_tumor
@@ -186,7 +197,7 @@ def kather_cr_train(args, model_teacher, model_student, classifier_teacher, clas
     for m in (model_student, classifier_student):
         m.train()
     te, st = eng.bind(model_teacher, classifier_teacher), eng.bind(model_student, classifier_student)
-    meters = _Meters(["loss", "loss_x", "loss_u", "acc"])
+    meters = _meters(eng, ["loss", "loss_x", "loss_u", "acc"])
     t0 = time.time()
     for batch_idx, (data_x, data_u) in enumerate(zip(labeled_train_loader, unlabeled_train_loader)):
         inputs_x, targets_x = data_x
@@ -207,7 +218,7 @@ def kather_cr_validate(args, model_student, classifier_student, val_loader, epoc
     model_student.eval()
     classifier_student.eval()
     st = eng.bind(model_student, classifier_student)
-    meters = _Meters(["loss", "acc"])
+    meters = _meters(eng, ["loss", "acc"])
     for batch_idx, (input, target) in enumerate(val_loader):
         r = eng.step_supervised(st, "ce", [input], target.reshape(-1).long(), train=False)
         meters.add(r["losses"], target.size(0))
@@ -235,7 +246,7 @@ def _rsp_epoch(args, model, classifier, loader, criterion, optimizer, epoch, tra
     model.train(train)
     classifier.train(train)
     net = eng.bind(model, classifier)
-    meters = _Meters(["loss", "acc"])
+    meters = _meters(eng, ["loss", "acc"])
     feats, targets = [], []
     t0 = time.time()
     for batch_idx, (input1, input2, input3, target) in enumerate(loader):
@@ -271,7 +282,7 @@ def cam_sup_train(args, model, classifier, tumor_labeled_train_loader, normal_la
     model.train()
     classifier.train()
     net = eng.bind(model, classifier)
-    meters = _Meters(["loss", "acc"])
+    meters = _meters(eng, ["loss", "acc"])
     feats, targets = [], []
     S = args.image_size
     for batch_idx, (tumor_data_x, normal_data_x) in enumerate(zip(tumor_labeled_train_loader, normal_labeled_train_loader)):
@@ -298,7 +309,7 @@ def bpq_sup_train(args, model, classifier, train_loader, criterion, optimizer, e
     model.train()
     classifier.train()
     net = eng.bind(model, classifier)
-    meters = _Meters(["loss"])
+    meters = _meters(eng, ["loss"])
     feats, targets = [], []
     for batch_idx, (input1, target) in enumerate(train_loader):
         x = input1.reshape(-1, 3, args.image_size, args.image_size)
@@ -319,7 +330,7 @@ def kather_sup_train(args, model, classifier, train_loader, criterion, optimizer
     model.train()
     classifier.train()
     net = eng.bind(model, classifier)
-    meters = _Meters(["loss", "acc"])
+    meters = _meters(eng, ["loss", "acc"])
     for batch_idx, (input, target) in enumerate(train_loader):
         x = input.reshape(-1, 3, args.image_size, args.image_size)                   # :57
         y = target.reshape(-1).long()

@@ -31,7 +31,8 @@ def _worker(rank, world, port, q):
     local.backward()
     g = W.grad.clone()
     dist.all_reduce(g)                                        # SUM, no division afterwards
-    total = sd.global_mean_of_scaled(local.detach())
+    total = local.detach().clone()
+    dist.all_reduce(total)                                    # per-rank losses are scaled by 1/global-count: their SUM is the global mean
     Wr = W.detach().clone().requires_grad_(True)
     ref = F.mse_loss(X @ Wr, Y)
     ref.backward()
@@ -47,6 +48,24 @@ def _worker(rank, world, port, q):
     y = (a - mean.float().view(1, -1, 1, 1)) / torch.sqrt(var.float().view(1, -1, 1, 1) + 1e-5)
     yref = sd.shard_batch(F.batch_norm(A, None, None, None, None, True, 0.1, 1e-5), rank, world)
     assert torch.allclose(y, yref, atol=1e-5)
+    # 4. the step functions' loss meters: per-rank shares stay local per step, ONE all-reduce when the meters are read
+    #    (steps._Meters; on the GPU the reduce is the engine's sslcr_comm_all_reduce_f32, here gloo stands in)
+    from ssl_cr_histo_amd.steps import _Meters
+    calls = []
+
+    def reduce(t):
+        calls.append(tuple(t.shape))
+        dist.all_reduce(t)
+    m = _Meters(["loss", "loss_x", "loss_u", "acc"], reduce, world)
+    share = [torch.tensor([0.3, 0.1, 0.2, 2.0]) * (rank + 1), torch.tensor([0.6, 0.2, 0.4, 1.0]) * (rank + 1)]
+    for sh in share:
+        m.add(sh, 4)                                          # 4 labeled images per rank and step -> global count 8
+    out = m.meters()
+    assert calls == [(2, 4)], calls                           # one collective for both steps
+    assert abs(out["loss"].avg - (0.9 + 1.8) / 2) < 1e-6 and abs(out["acc"].avg - (6.0 / 8 + 3.0 / 8) / 2) < 1e-6
+    m.add(share[0], 4)
+    out = m.meters()                                          # a later read reduces only the new row
+    assert calls == [(2, 4), (1, 4)] and abs(out["loss"].avg - (0.9 + 1.8 + 0.9) / 3) < 1e-6
     q.put((rank, "ok"))
     dist.destroy_process_group()
 

@@ -388,8 +388,10 @@ def test_virtual_ranks_equal_the_single_device_step(world, workload, dtype):
             res = eng.step_ssl_cr(te, st, kind, x[lo_x:hi_x], y[lo_x:hi_x], u_w[lo_u:hi_u], u_s[lo_u:hi_u], 0.7, nx_global=nx, nu_global=nu)
         grads = [st.grad(i).cpu().double() for i in range(len(st.params))]
         st.optimizer_step(opt)
+        # the loss meters' collective (steps._Meters -> sslcr_comm_all_reduce_f32): per-rank shares -> the global losses, on every rank
+        summed = eng.all_reduce_sum(res["losses"].clone())
         torch.cuda.current_stream().synchronize()
-        return dict(losses=res["losses"].cpu().double(), grads=grads, state=state_of(ms, cs))
+        return dict(losses=res["losses"].cpu().double(), summed=summed.cpu().double(), grads=grads, state=state_of(ms, cs))
 
     single = one_step(E.Engine(DEV, dtype), 0, 1)
     vc = E.VirtualComm(world)
@@ -405,6 +407,8 @@ def test_virtual_ranks_equal_the_single_device_step(world, workload, dtype):
         # flat across conv1 .. layer4, losses equal to 1e-5); worlds 2 and 4 hold the arithmetic to 2e-5
         tg, tsn = 3e-3, 1e-3
     total = sum(o["losses"] for o in ranks)
+    for o in ranks:
+        assert torch.allclose(o["summed"], total, rtol=1e-6, atol=1e-7), (o["summed"], total)
     if dtype == "fp32":
         assert torch.allclose(total[:3], single["losses"][:3], rtol=tl, atol=1e-7), (total, single["losses"])
     else:
