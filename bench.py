@@ -29,7 +29,8 @@ sys.path.insert(0, ROOT)
 
 F_FWD = 2 * 2368733184            # backbone forward FLOPs per 256x256 image
 F_BWD_FULL = 2 * F_FWD - 0.308e9  # + dgrad + wgrad, no dgrad for conv1
-PMC_FILE = os.path.join("profiles", "r02_pmc_step.json")     # tools/pmc_step.sh: counters of THIS command, per kernel
+PMC_FILE = os.path.join("profiles", "r03_pmc_step.json")     # fallback only (tools/pmc_step.sh on the builder's lease): the line's
+                                                              # counters are measured IN this run by pmc_in_run() when rocprofv3 is there
 
 
 def parse():
@@ -37,7 +38,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="ssl_cr", choices=["ssl_cr", "fwd", "rsp"])
+    ap.add_argument("--workload", default="ssl_cr", choices=["ssl_cr", "fwd", "rsp", "cam_cr"],
+                    help="ssl_cr = BreastPathQ consistency step (headline, config 4); cam_cr = Camelyon consistency step (config 5: CE + "
+                         "hard-pseudo-label CE, two class loaders, SGD-Nesterov; use --batch_size 128 for its per-GPU shape)")
     ap.add_argument("--batch_size", type=int, default=64, help="per-GPU --batch_size b (ssl_cr: 3b labeled + 7b unlabeled)")
     ap.add_argument("--mu", type=int, default=7)
     ap.add_argument("--image_size", type=int, default=256)
@@ -54,7 +57,8 @@ def parse():
                     help="1 = backward's weight-gradient launches on a second HIP stream (measured neutral: 18.84 vs 18.76 ms/step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-also", action="store_true", help="skip the other configurations (forward-only, RSP, frozen, fp32 parity)")
+    ap.add_argument("--no-also", action="store_true", help="skip the other configurations (forward-only, RSP, frozen, fp32 parity, config 5)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc passes (MFMA busy, HBM traffic per kernel)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--also-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -76,7 +80,7 @@ def build_nets(device, classes=1, triplet=False):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-CPU_BASELINE_WALL_S = 60.0        # hard bound on the whole leg (the child process is killed at the deadline)
+CPU_BASELINE_WALL_S = 100.0       # hard bound on the whole leg (the child process is killed at the deadline)
 
 
 def cpu_baseline_child(args):
@@ -94,7 +98,7 @@ def cpu_baseline_child(args):
     u_s = torch.randint(0, 256, (nu, 3, hw, hw), generator=g).float()
     y = torch.rand(nx, generator=g)
 
-    def leg(threads, faithful, budget_s, warm=1):
+    def leg(threads, faithful, budget_s, warm=3, timed_steps=10):
         print(json.dumps({"started": True, "threads": threads, "variant": "faithful" if faithful else "algorithmic"}), flush=True)
         torch.set_num_threads(threads)
 
@@ -109,7 +113,7 @@ def cpu_baseline_child(args):
             v.requires_grad_(i >= args.modules_student)
         opt = S.Adam(ps.values(), 1e-4, (0.9, 0.999), 1e-8, 1e-4)
         times, t_begin = [], time.time()
-        for it in range(warm + 5):                                     # median of at most 5 timed steps
+        for it in range(warm + timed_steps):                           # 3 warm-up + >= 10 timed steps, median
             t0 = time.time()
             S.ssl_cr_step("mse", ps, bs, pt, bt, opt, x, y, u_w, u_s, 1.0, faithful=faithful)
             if it >= warm:
@@ -124,27 +128,25 @@ def cpu_baseline_child(args):
     ncpu = os.cpu_count() or 1
     # torch-CPU convolutions on a 34-image batch do not scale with the thread count: measured on the MI355X box's 2 x EPYC 9575F
     # (256 logical cores) 0.29 s/step at 16 threads, 0.33 at 32, 0.69 at 64, 1.49 at 128, and not one step in 3 min at 256 -- so
-    # the legs of record are 16 and 32 threads, then one single-thread step, then one step each at half and at all logical
-    # cores for as long as the wall bound allows
+    # the legs of record are 16 and 32 threads with BASELINE.md section 3's 3 warm-up + 10 timed steps (about 25 s together), then
+    # one single-thread step for the per-core order of magnitude.  The half / all-core legs of round 2 are gone: they are slower
+    # than 16 threads by 5x and more, and the all-core one never finished
     small = [t for t in (16, 32) if t <= ncpu] or [ncpu]
     for t in small:
-        leg(t, True, 8.0)
-        leg(t, False, 4.0)
-    leg(1, False, 0.0, warm=0)              # one single-thread step, no warm-up: order of magnitude per core
-    for t in (ncpu // 2, ncpu):
-        if t > small[-1]:
-            leg(t, False, 0.0, warm=0)
+        leg(t, True, 30.0)
+        leg(t, False, 15.0)
+    leg(1, False, 0.0, warm=0, timed_steps=1)     # one single-thread step, no warm-up: order of magnitude per core
 
 
 def cpu_baseline(args):
     """The oracle (CPU restatement of the reference step, torch-CPU fp32, proved equal to the reference's train() on the
     committed goldens) timed on this box's host cores: config C4 at b=2, mu=7 (student 20 / teacher 14 images, 34 distinct
     patches per step), full fine-tune, Adam -- FAITHFUL (three backbone passes per image, models/net.py:88-90: what the
-    reference executes) and ALGORITHMIC (one pass), at 16 and 32 threads (median of up to 5 timed steps after one warm-up), one
-    single-thread step of the algorithmic variant, then one algorithmic step at half and at all logical cores as far as the wall
-    bound allows (more threads are slower on this batch, see cpu_baseline_child).  Bounded: every leg stops adding steps once its
-    share is used, and the whole thing runs in a child process that is killed at CPU_BASELINE_WALL_S (legs finished by then
-    count).  `value` = the best faithful leg (the reference-equivalent baseline of record)."""
+    reference executes) and ALGORITHMIC (one pass), at 16 and 32 threads (3 warm-up steps, median of 10 timed
+    steps) and one single-thread step of the algorithmic variant (more threads are slower on this batch, see cpu_baseline_child).
+    Bounded: every leg stops adding steps once its share is used, and the whole thing runs in a child process that is killed at
+    CPU_BASELINE_WALL_S (legs finished by then count).  `value` = the best faithful leg (the reference-equivalent baseline of
+    record)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--image_size", str(args.image_size), "--mu", str(args.mu),
            "--modules_student", str(args.modules_student)]
     env = dict(os.environ)
@@ -182,7 +184,8 @@ def cpu_baseline(args):
             "sample": f"oracle ssl_cr_step (CPU restatement of eval_BreastPathQ_SSL_CR.train, torch-CPU fp32), config C4 at b={b} mu={mu}: "
                       f"{3 * b} labeled + {mu * b}+{mu * b} unlabeled {hw}x{hw} patches = {best['patches_per_step']} distinct patches/step, "
                       f"modules_student={args.modules_student}, Adam; value = FAITHFUL variant (3 backbone passes per image like "
-                      f"models/net.py:88-90) at {best['threads']} threads, median of {best['timed_steps']} timed step(s) after 1 warm-up "
+                      f"models/net.py:88-90) at {best['threads']} threads, median of {best['timed_steps']} timed step(s) after "
+                      f"{best['warmup_steps']} warm-up "
                       f"({best['s_per_step']} s/step); all legs in `legs`",
             "host": {"cpu": cpu_model, "logical_cores": ncpu}, "legs": legs, "wall_s": round(time.time() - t0, 1),
             "timed_out": timed_out}
@@ -224,6 +227,36 @@ def make_workload(name, eng, args, device, rank, world, modules_student=None):
                "global_batch_patches": (nx + 2 * nu) * world, "parallelism": f"dp{world}", "backward": ms_freeze < 60,
                "bn_sync": bool(args.bn_sync) if world > 1 else None, "aux_stream": bool(args.aux_stream),
                "wgrad_stream": bool(args.wgrad_stream)}
+        return step, nx + 2 * nu, flops, cfg, (mt, ct, ms, cs, opt)
+    if name == "cam_cr":
+        # eval_Camelyon_SSL_CR.train (:94-121): tumor + normal labeled loaders (b x 3 images each), tumor + normal unlabeled loaders (b x mu each)
+        nx, nu = 2 * 3 * b, 2 * mu * b
+        mt, ct = build_nets(device, classes=2)
+        ms, cs = build_nets(device, classes=2)
+        for m in (mt, ct):
+            m.eval()
+        for m in (ms, cs):
+            m.train()
+        for p in list(mt.parameters()) + list(ct.parameters()):
+            p.requires_grad = False
+        for i, (_, p) in enumerate(ms.named_parameters()):
+            p.requires_grad = i >= ms_freeze
+        te, st = eng.bind(mt, ct), eng.bind(ms, cs)
+        opt = torch.optim.SGD(filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters())), lr=5e-4, momentum=0.9,
+                              weight_decay=wd, nesterov=True)
+        x = synth_u8((nx, 3, hw, hw), 1234 + rank, device)
+        u_w = synth_u8((nu, 3, hw, hw), 2234 + rank, device)
+        u_s = synth_u8((nu, 3, hw, hw), 3234 + rank, device)
+        y = torch.randint(0, 2, (nx,), generator=torch.Generator().manual_seed(4234 + rank)).to(device)
+
+        def step():
+            r = eng.step_ssl_cr(te, st, "ce", x, y, u_w, u_s, 1.0)
+            st.optimizer_step(opt)
+            return r
+        flops = nu * F_FWD + (nx + nu) * (F_FWD + (F_BWD_FULL if ms_freeze == 0 else 0))
+        cfg = {"workload": f"eval_Camelyon_SSL_CR.train step, per-GPU --batch_size {b} --mu {mu}: student {nx}+{nu}, teacher {nu} "
+                           f"({nx + 2 * nu} distinct {hw}x{hw} uint8 patches/step/GPU), modules_student={ms_freeze}, SGD-Nesterov",
+               "global_batch_patches": (nx + 2 * nu) * world, "parallelism": f"dp{world}", "backward": ms_freeze < 60}
         return step, nx + 2 * nu, flops, cfg, (mt, ct, ms, cs, opt)
     if name == "fwd":
         n = 4 * b
@@ -290,6 +323,37 @@ def also_child(args):
     rec("parity_mode_fp32", "ssl_cr", eng32, 4, 2)
     also["parity_mode_fp32"]["note"] = ("exact-parity engine mode (v_mfma_f32_16x16x4_f32, fp32 storage): the mode that holds the "
                                         "north-star 1e-3 against the reference goldens; peak = 157.3 TF fp32 matrix")
+    del eng32
+    torch.cuda.empty_cache()
+    # BASELINE config 5 at its per-GPU shape (eval_Camelyon_SSL_CR.py --batch_size 1024 over 8 GPUs -> b = 128 per class loader:
+    # student 768 + 1792 = 2560, teacher 1792 images), in bf16 mode and in the fp8 mode (e4m3 forward convs of layers 2-4)
+    import copy
+    a5 = copy.copy(args)
+    a5.batch_size = 128
+
+    def rec5(tag, dtype):
+        e5 = eng if dtype == "bf16" else E.Engine(device, dtype)
+        s, p, fl, c, k = make_workload("cam_cr", e5, a5, device, 0, 1)
+        t = timed(s, 3, 5, barrier)
+        r = {"images_per_s": round(p * 5 / t, 1), "ms_per_step": round(t / 5 * 1e3, 3), "steps": 5, "dtype": dtype,
+             "achieved_tflops_algorithmic": round(fl / (t / 5) / 1e12, 2), "workload": c["workload"]}
+        e5.profile(True)
+        for _ in range(2):
+            s()
+        torch.cuda.synchronize()
+        rows = [q for q in e5.profile_table() if q["flops"] > 0]
+        e5.profile(False)
+        d = next((q for q in rows if "fp8" in q["name"]), rows[0]) if dtype == "fp8" else rows[0]
+        pk = 5000.0 if "fp8" in d["name"] else 2500.0
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        r["roofline"] = {"bound": "mfma", "kernel": d["name"], "achieved": round(ach, 2), "peak": pk, "unit": "TFLOP/s",
+                         "frac": round(ach / pk, 4), "launches": d["launches"], "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                         "time_share_of_step": round(d["ms"] / (r["ms_per_step"] * 2), 3)}
+        also[tag] = r
+        del s, k
+        torch.cuda.empty_cache()
+    rec5("bf16_config5", "bf16")
+    rec5("fp8_config5", "fp8")
     print(json.dumps(also), flush=True)
 
 
@@ -299,14 +363,7 @@ def also_records(args):
     in one process their launches would be averaged into the headline's per-kernel durations)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--also-child", "--batch_size", str(args.batch_size), "--mu", str(args.mu),
            "--image_size", str(args.image_size)]
-    env = {k: v for k, v in os.environ.items()
-           if not (k.startswith(("ROCPROF", "ROCP_", "ROCTX", "ROCTRACER")) or k in ("HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"))}
-    if "LD_PRELOAD" in env:
-        kept = [x for x in env["LD_PRELOAD"].replace(":", " ").split() if "rocprof" not in x and "roctracer" not in x and "roctx" not in x]
-        if kept:
-            env["LD_PRELOAD"] = ":".join(kept)
-        else:
-            del env["LD_PRELOAD"]
+    env = _clean_profiler_env()
     try:
         proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
     except subprocess.TimeoutExpired:
@@ -315,6 +372,58 @@ def also_records(args):
     if proc.returncode != 0 or not lines:
         return {"error": f"also child exited with {proc.returncode}", "stderr_tail": proc.stderr[-400:]}
     return json.loads(lines[-1])
+
+
+def _clean_profiler_env():
+    """this process's environment without a surrounding rocprofv3's hooks (children get their own profiler or none)"""
+    env = {k: v for k, v in os.environ.items()
+           if not (k.startswith(("ROCPROF", "ROCP_", "ROCTX", "ROCTRACER")) or k in ("HSA_TOOLS_LIB", "HSA_TOOLS_REPORT_LOAD_FAILURE"))}
+    if "LD_PRELOAD" in env:
+        kept = [x for x in env["LD_PRELOAD"].replace(":", " ").split() if "rocprof" not in x and "roctracer" not in x and "roctx" not in x]
+        if kept:
+            env["LD_PRELOAD"] = ":".join(kept)
+        else:
+            del env["LD_PRELOAD"]
+    return env
+
+
+PMC_PASSES = ["SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"]
+
+
+def pmc_in_run(args):
+    """MFMA-busy and HBM-traffic counters of THIS command's step, measured now: three counter-only `rocprofv3 --pmc ... --kernel-trace`
+    passes (SQ + GRBM; FETCH_SIZE; WRITE_SIZE -- the TCC slots do not fit one pass, MI355X_MICROARCH.md) over a short child run of the
+    same workload, reduced per kernel template instance by tools/pmc_step_reduce.py.  -> (document | None, note)"""
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_step_reduce
+    out = tempfile.mkdtemp(prefix="sslcr_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "2", "--no-roofline", "--no-cpu-baseline", "--no-also",
+             "--no-pmc", "--workload", args.workload, "--batch_size", str(args.batch_size), "--mu", str(args.mu), "--image_size",
+             str(args.image_size), "--modules_student", str(args.modules_student), "--dtype", args.dtype]
+    env = _clean_profiler_env()
+    env["TMPDIR"] = "/tmp"
+    t0 = time.time()
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            cmd = [exe, "--pmc"] + counters.split() + ["--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, f"pass{i}"), "-o", "pmc",
+                                                        "--"] + child
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd="/tmp", timeout=150)
+            if r.returncode != 0:
+                return None, f"rocprofv3 pass {i} exited with {r.returncode}: {r.stdout[-300:]}"
+        doc = pmc_step_reduce.reduce_dir(out, command="python bench.py " + " ".join(child[2:]))
+    except subprocess.TimeoutExpired:
+        return None, "a rocprofv3 --pmc pass did not finish in 150 s"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    if not doc["kernels"]:
+        return None, "the rocprofv3 passes produced no counter rows"
+    doc["wall_s"] = round(time.time() - t0, 1)
+    return doc, "ok"
 
 
 def spawn_ranks(args):
@@ -372,6 +481,9 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = patches * world * args.steps / dt
     crank, cworld, transport = eng.comm_info()
+    if world > 1 and (cworld != world or transport != "rccl"):
+        raise SystemExit(f"bench.py --gpus {world}: the engine's communicator reports {cworld} rank(s) over '{transport}' -- the RCCL "
+                         "communicator was not built; refusing to print a multi-GPU number for independent replicas")
 
     out = {"metric": "images/sec (ResNet18 SSL_CR step, 256x256 bf16 synthetic patches; whole job)" if args.workload == "ssl_cr"
            else f"images/sec ({args.workload})",
@@ -381,6 +493,15 @@ def main():
            "per_gpu_images_per_s": round(value / world, 1),
            "achieved_tflops_per_gpu_algorithmic": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
            "ranks_seen": cworld, "collective_transport": transport}
+
+    cpu_thread, cpu_box = None, {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "ssl_cr":
+        # the CPU baseline (host cores only, a child process with the GPU hidden) runs while this process does the roofline leg,
+        # the counter passes and the other configurations on the GPU: the two do not share a resource, and the default run
+        # stays within a few minutes
+        import threading
+        cpu_thread = threading.Thread(target=lambda: cpu_box.update(r=cpu_baseline(args)))
+        cpu_thread.start()
 
     if rank == 0 and not args.no_roofline:
         # roofline leg: same steps again with every conv launch bracketed by HIP events on its own stream
@@ -394,9 +515,17 @@ def main():
         peak = 157.3 if args.dtype == "fp32" else 2500.0
         hbm_rows = [r for r in rows if r["flops"] == 0]
         rows = [r for r in rows if r["flops"] > 0]
-        pmc = {}
-        if os.path.exists(os.path.join(ROOT, PMC_FILE)) and args.workload == "ssl_cr" and args.dtype == "bf16":
+        # counters: measured now by child rocprofv3 --pmc passes over this workload; the committed file is only the fallback
+        pmc, pmc_src, pmc_measured, pmc_note = {}, None, False, "skipped (--no-pmc)"
+        if not args.no_pmc and world == 1:
+            doc, pmc_note = pmc_in_run(args)
+            if doc:
+                pmc = {e["kernel"]: e for e in doc["kernels"]}
+                pmc_src, pmc_measured = f"rocprofv3 --pmc child passes of this run ({doc['wall_s']} s)", True
+        if not pmc and os.path.exists(os.path.join(ROOT, PMC_FILE)) and args.workload == "ssl_cr" and args.dtype == "bf16":
             pmc = {e["kernel"]: e for e in json.load(open(os.path.join(ROOT, PMC_FILE)))["kernels"]}
+            pmc_src = PMC_FILE
+        out["pmc_status"] = {"measured_in_run": pmc_measured, "source": pmc_src, "note": pmc_note}
 
         def pmc_of(name):
             for k, e in pmc.items():
@@ -412,7 +541,8 @@ def main():
                       "time_share_of_step": round(d["ms"] / (ms_per_step * nprof), 3)}
             if e:
                 # rocprofv3 --pmc passes over this same command (tools/pmc_step.sh), averaged over the kernel's launches of a step
-                common["pmc"] = {"source": PMC_FILE, "mfma_busy": e.get("mfma_busy"), "valu_per_mfma": e.get("valu_per_mfma"),
+                common["pmc"] = {"measured_in_run": pmc_measured, "source": pmc_src, "mfma_busy": e.get("mfma_busy"),
+                                 "valu_per_mfma": e.get("valu_per_mfma"),
                                  "traffic_over_algorithmic": round(e["traffic_bytes_per_launch"] / (d["bytes"] / d["launches"]), 3)
                                  if e.get("traffic_bytes_per_launch") else None}
             if d["flops"] > 0:
@@ -449,15 +579,21 @@ def main():
                 busy = [(m, e["mfma_busy"]) for m, e in busy if e and e.get("mfma_busy") is not None]
                 if busy:
                     out["conv_all"]["mfma_busy_time_weighted"] = round(sum(m * b for m, b in busy) / sum(m for m, _ in busy), 4)
-                    out["conv_all"]["mfma_busy_source"] = PMC_FILE
+                    out["conv_all"]["mfma_busy_source"] = pmc_src
+                    out["conv_all"]["mfma_busy_measured_in_run"] = pmc_measured
+                    out["mfma_util_pct"] = round(100.0 * out["conv_all"]["mfma_busy_time_weighted"], 1)    # BASELINE metric's "MFMA util %"
+                tr = [e.get("traffic_bytes_per_launch", 0) * e["dispatches_measured"] for e in pmc.values() if e.get("traffic_bytes_per_launch")]
+                if tr and pmc_measured:
+                    out["hbm_traffic_gb_per_step"] = round(sum(tr) / 4 / 1e9, 2)      # the child runs 2 warm-up + 2 timed steps
 
     if rank == 0 and world == 1 and not args.no_also and args.workload == "ssl_cr" and args.dtype == "bf16":
         # the other BASELINE.json configurations on the same box (short runs: they are records, not the headline)
         del keep
         torch.cuda.empty_cache()
         out["also"] = also_records(args)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "ssl_cr":
-        out["cpu_baseline"] = cpu_baseline(args)
+    if cpu_thread is not None:
+        cpu_thread.join()
+        out["cpu_baseline"] = cpu_box.get("r")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
