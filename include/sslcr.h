@@ -262,6 +262,35 @@ typedef struct sslcr_weak_aug_desc {
 } sslcr_weak_aug_desc;
 int sslcr_weak_augment(const sslcr_weak_aug_desc* d, void* stream);
 
+/* ---- device-side strong augmentation, the colour ops of the reference's RandAugment pool ("next" row f4) on a uint8 batch in HBM.
+ *      As with sslcr_weak_augment the random draws stay on the host, in the reference's order (ssl_cr_histo_amd/augment.py);
+ *      the kernels are the deterministic per-pixel arithmetic.
+ *
+ *      sslcr_hed_colour_augment: models/randaugment.py:17-48 colour_augmentation() -- rgb2hed, per-image shift of the three stain
+ *      channels, hed2rgb, (x * 255).astype(uint8) -- in float64, operation for operation as scikit-image 0.15.0 (requirements.txt:369)
+ *      computes it (see csrc/augment.hip); replaces the reference's per-pixel Python loop (:35-38). */
+typedef struct sslcr_colour_aug_desc {
+  const uint8_t* src;       /* [N][3][H][W] (hwc=0, what the stem ingests) or [N][H][W][3] (hwc=1, the PIL/numpy layout) */
+  uint8_t* dst;             /* same layout; may alias src */
+  const double* shift;      /* [N][3] device doubles: (hmod, dmod, emod) of :30-32 */
+  const uint8_t* apply;     /* [N] or NULL: 0 = the image is copied unchanged (RandAugment did not pick this op for it) */
+  double hed_from_rgb[9];   /* row-major 3x3: skimage.color.hed_from_rgb = inv(rgb_from_hed) */
+  double rgb_from_hed[9];
+  int N, H, W, hwc;
+} sslcr_colour_aug_desc;
+int sslcr_hed_colour_augment(const sslcr_colour_aug_desc* d, void* stream);
+/*      sslcr_brightness_contrast: models/randaugment.py:93-103 Brightness() / Contrast() = albumentations 0.1.8
+ *      (requirements.txt:10) RandomBrightnessContrast: clip(float32(img) * alpha + beta * mean(img), 0, max(img)).astype(uint8),
+ *      mean and max over the whole image. */
+typedef struct sslcr_brightness_contrast_desc {
+  const uint8_t* src; uint8_t* dst;      /* [N][3][H][W] or [N][H][W][3]: the map is layout-blind; dst may alias src */
+  const double* alpha_beta; /* [N][2] device doubles: alpha = 1 + contrast draw, beta = brightness draw */
+  const uint8_t* apply;     /* [N] or NULL */
+  unsigned long long* stats;/* workspace [N][2] (sum, max), zeroed by the call */
+  int N, H, W;
+} sslcr_brightness_contrast_desc;
+int sslcr_brightness_contrast(const sslcr_brightness_contrast_desc* d, void* stream);
+
 /* ==================================================================================================
  * Engine: the whole ResNet18 TripletNet(_Finetune)+head graph, forward / backward / update, orchestrated
  * natively (one C call per step).  Replaces the step bodies of the reference's train()/validate():

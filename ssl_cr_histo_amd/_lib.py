@@ -59,6 +59,10 @@ OptDesc = _S("OptDesc", [("kind", i32), ("lr", f32), ("beta1", f32), ("beta2", f
                          ("momentum", f32), ("bc1", f32), ("bc2", f32), ("first_step", i32), ("grad_scale", f32)])
 WeakAugDesc = _S("WeakAugDesc", [("src", vp), ("dst", vp), ("params", vp)] +
                  [(k, i32) for k in ("N", "SH", "SW", "OH", "OW", "src_hwc")])
+ColourAugDesc = _S("ColourAugDesc", [("src", vp), ("dst", vp), ("shift", vp), ("apply", vp), ("hed_from_rgb", f64 * 9),
+                                     ("rgb_from_hed", f64 * 9), ("N", i32), ("H", i32), ("W", i32), ("hwc", i32)])
+BrightnessContrastDesc = _S("BrightnessContrastDesc", [("src", vp), ("dst", vp), ("alpha_beta", vp), ("apply", vp), ("stats", vp),
+                                                       ("N", i32), ("H", i32), ("W", i32)])
 PackDesc = _S("PackDesc", [("w", vp), ("w_fwd", vp), ("w_dgrad", vp), ("gamma", vp), ("beta", vp), ("rmean", vp),
                            ("rvar", vp), ("eps", f32), ("bias_out", vp)] + [(k, i32) for k in ("K", "C", "R", "S", "dgrad_flip")])
 
@@ -102,6 +106,8 @@ SIGNATURES = {
     "sslcr_pack_conv": (i32, [i32, P(PackDesc), vp]),
     "sslcr_pack_stem": (i32, [i32, P(PackDesc), vp]),
     "sslcr_weak_augment": (i32, [P(WeakAugDesc), vp]),
+    "sslcr_hed_colour_augment": (i32, [P(ColourAugDesc), vp]),
+    "sslcr_brightness_contrast": (i32, [P(BrightnessContrastDesc), vp]),
 }
 
 _lib = None

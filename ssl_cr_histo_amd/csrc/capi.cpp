@@ -189,6 +189,16 @@ int sslcr_weak_augment(const sslcr_weak_aug_desc* d, void* stream) {
   NEED(d->N > 0 && d->OH > 0 && d->OW > 0 && d->OH <= d->SH && d->OW <= d->SW, "crop larger than the source");
   return check(launch_weak_augment(*d, (hipStream_t)stream), "weak_augment");
 }
+int sslcr_hed_colour_augment(const sslcr_colour_aug_desc* d, void* stream) {
+  NEED(d && d->src && d->dst && d->shift, "null");
+  NEED(d->N > 0 && d->H > 0 && d->W > 0, "empty batch");
+  return check(launch_hed_colour(*d, (hipStream_t)stream), "hed_colour_augment");
+}
+int sslcr_brightness_contrast(const sslcr_brightness_contrast_desc* d, void* stream) {
+  NEED(d && d->src && d->dst && d->alpha_beta && d->stats, "null");
+  NEED(d->N > 0 && d->H > 0 && d->W > 0, "empty batch");
+  return check(launch_brightness_contrast(*d, (hipStream_t)stream), "brightness_contrast");
+}
 int sslcr_pack_stem(int dtype, const sslcr_pack_desc* d, void* stream) {
   DT_OK(dtype);
   NEED(d && d->w && d->w_fwd && d->K == 64 && d->C == 3 && d->R == 7 && d->S == 7, "stem shape");

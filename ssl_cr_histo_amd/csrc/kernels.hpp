@@ -85,6 +85,8 @@ hipError_t launch_loss(const LossArgs& a, hipStream_t st);
 hipError_t launch_softmax_col(const float* logits, float* out, int n, int C, int col, hipStream_t st);
 // augment.hip
 hipError_t launch_weak_augment(const sslcr_weak_aug_desc& a, hipStream_t st);
+hipError_t launch_hed_colour(const sslcr_colour_aug_desc& a, hipStream_t st);
+hipError_t launch_brightness_contrast(const sslcr_brightness_contrast_desc& a, hipStream_t st);
 // optim.hip
 hipError_t launch_optimizer(const TensorDesc* d_descs, int ntensors, int max_n, const OptArgs& o, hipStream_t st);
 constexpr int OPT_CHUNK = 2048;     // elements per work-list entry

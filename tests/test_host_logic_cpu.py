@@ -176,3 +176,31 @@ def test_bench_spawns_ranks_itself_and_refuses_more_gpus_than_visible(monkeypatc
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "3"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_colour_op_restatements_and_draw_orders():
+    """row f4 oracle (no GPU): the stain round trip rgb2hed -> hed2rgb of the restated scikit-image 0.15.0 functions is the identity
+    up to the final truncation, a zero shift therefore changes no byte by more than one LSB, the product's parameter helpers draw
+    exactly like the oracle's, and the brightness / contrast restatement clips at the image's own maximum."""
+    import random
+
+    import numpy as np
+    from oracle import augment_ref as AR
+    from ssl_cr_histo_amd import augment as A
+    img = np.random.RandomState(1).randint(0, 256, (32, 24, 3), dtype=np.uint8)
+    back = AR.hed2rgb(AR.rgb2hed(img))
+    assert np.abs(back - img / 255.0).max() < 1e-12
+    same = AR.colour_augmentation(img, 0.0, 0.0, 0.0)
+    assert np.abs(same.astype(int) - img.astype(int)).max() <= 1
+    assert np.allclose(np.dot(AR.HED_FROM_RGB, AR.RGB_FROM_HED), np.eye(3), atol=1e-12)
+    inv, fwd = A._hed_matrices()
+    assert inv == AR.HED_FROM_RGB.reshape(-1).tolist() and fwd == AR.RGB_FROM_HED.reshape(-1).tolist()
+    ra, rb = random.Random(4), random.Random(4)
+    assert [A.colour_shifts(ra) for _ in range(5)] == [AR.draw_colour_shifts(rb) for _ in range(5)]
+    assert [A.brightness_contrast_params(ra, contrast_limit=0.1) for _ in range(8)] == \
+           [AR.draw_brightness_contrast(rb, contrast_limit=0.1) for _ in range(8)]
+    dark = (img // 2).astype(np.uint8)
+    out = AR.brightness_contrast_adjust(dark, 1.2, 0.2)
+    assert out.max() == dark.max() and out.dtype == np.uint8
+    assert [p[0] for p in A.RandAugmentDevice.POOL] == ["HSV", "Noise", "Scale_Resize_Crop", "Shift_Scale_Rotate", "Color", "Blur_img",
+                                                         "Brightness", "Contrast", "Rotate_Crop"]      # models/randaugment.py:105-117

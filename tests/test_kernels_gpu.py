@@ -679,3 +679,81 @@ def test_transform_fix_geometric_both_branches():
     g = torch.Generator().manual_seed(5)
     mine = augment.fix_params(n, (sh, sw), size, g)
     assert torch.equal(mine[0], pw) and torch.equal(mine[1], ps)
+
+
+@pytest.mark.parametrize("hwc", [False, True])
+def test_hed_colour_augmentation(hwc):
+    """row f4: colour_augmentation (models/randaugment.py:17-48) on the device against the numpy restatement of the same lines on
+    top of scikit-image 0.15.0's published rgb2hed / hed2rgb (oracle/augment_ref.py).  Both sides are float64; the kernel's log / exp
+    are the ROCm device library's, so a value whose x*255 lands within an ulp of an integer could truncate differently: bytes are
+    required equal up to one LSB (modulo the reference's own uint8 wrap-around), and in fact all but a handful must be identical."""
+    import random
+    from oracle import augment_ref as AR
+    from ssl_cr_histo_amd import augment as A
+    N, H, W = 6, 96, 80
+    rs = np.random.RandomState(123)
+    src = rs.randint(0, 256, (N, H, W, 3), dtype=np.uint8)
+    src[0, :8, :8] = 0
+    src[0, 8:16, :8] = 255                                     # saturated corners: the wrap-around of (x * 255).astype(uint8)
+    rng_a, rng_b = random.Random(11), random.Random(11)
+    shifts = [A.colour_shifts(rng_a) for _ in range(N)]
+    assert shifts == [AR.draw_colour_shifts(rng_b) for _ in range(N)]
+    shifts[1] = (0.12, -0.09, 0.11)                            # far outside the usual draw: drives values below 0 and above 1
+    apply = [True, True, True, False, True, True]
+    want = np.stack([AR.colour_augmentation(src[i], *shifts[i]) if apply[i] else src[i] for i in range(N)])
+    t = torch.from_numpy(src)
+    dev = (t if hwc else t.permute(0, 3, 1, 2)).contiguous().to(DEV)
+    got = A.hed_colour_augment(dev, shifts, apply, hwc=hwc)
+    got = (got if hwc else got.permute(0, 2, 3, 1)).cpu().numpy()
+    assert np.array_equal(got[3], src[3])
+    diff = (got.astype(np.int16) - want.astype(np.int16)) % 256
+    diff = np.minimum(diff, 256 - diff)
+    assert diff.max() <= 1, diff.max()
+    assert (diff != 0).sum() <= 8, (diff != 0).sum()
+    assert (want != src).mean() > 0.5                          # the op really changed the images
+
+
+def test_brightness_contrast_and_the_randaugment_colour_subset():
+    """row f4: Brightness / Contrast (models/randaugment.py:93-103 -> albumentations 0.1.8 brightness_contrast_adjust) bit-exact
+    against the float32 restatement, and RandAugmentDevice drawing like RandAugment.__call__ (:130-144) for the device-served ops."""
+    import random
+    from oracle import augment_ref as AR
+    from ssl_cr_histo_amd import augment as A
+    N, H, W = 5, 64, 48
+    rs = np.random.RandomState(5)
+    src = rs.randint(0, 256, (N, H, W, 3), dtype=np.uint8)
+    src[2] = rs.randint(0, 180, (H, W, 3), dtype=np.uint8)     # max(img) < 255: the @clipped bound is the image's own maximum
+    ab = [(1.15, 0.1), (0.85, -0.2), (1.2, 0.2), (1.0, 0.0), (0.8, 0.15)]
+    apply = [True, True, True, True, False]
+    want = np.stack([AR.brightness_contrast_adjust(src[i], *ab[i]) if apply[i] else src[i] for i in range(N)])
+    dev = torch.from_numpy(src).permute(0, 3, 1, 2).contiguous().to(DEV)
+    got = A.brightness_contrast(dev, ab, apply).permute(0, 2, 3, 1).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert want[2].max() <= src[2].max()
+    # draw order of the parameter helpers == the oracle's restatement of the library's
+    ra, rb = random.Random(9), random.Random(9)
+    assert [A.brightness_contrast_params(ra, brightness_limit=0.1) for _ in range(6)] == \
+           [AR.draw_brightness_contrast(rb, brightness_limit=0.1) for _ in range(6)]
+    # RandAugment(n=2, m=10) restricted to the colour ops: per image choices(k=2), randint(1, m), then the op's own draws
+    class ColourOnly(A.RandAugmentDevice):
+        POOL = tuple(p for p in A.RandAugmentDevice.POOL if p[0] in ("Color", "Brightness", "Contrast"))
+    aug = ColourOnly(2, 10, random.Random(21), np.random.RandomState(22))
+    out = aug(dev).permute(0, 2, 3, 1).cpu().numpy()
+    rng, nrng = random.Random(21), np.random.RandomState(22)
+    ref = []
+    for i in range(N):
+        img = src[i]
+        for name, lo, hi in rng.choices(ColourOnly.POOL, k=2):
+            v = nrng.randint(1, 10)
+            val = (float(v) / 30) * float(hi - lo) + lo
+            if name == "Color":
+                img = AR.colour_augmentation(img, *AR.draw_colour_shifts(rng))
+            else:
+                kw = {"brightness_limit": val} if name == "Brightness" else {"contrast_limit": val}
+                on, alpha, beta = AR.draw_brightness_contrast(rng, **kw)
+                if on:
+                    img = AR.brightness_contrast_adjust(img, alpha, beta)
+        ref.append(img)
+    d = (out.astype(np.int16) - np.stack(ref).astype(np.int16)) % 256
+    d = np.minimum(d, 256 - d)
+    assert d.max() <= 2 and (d != 0).mean() < 1e-3, (d.max(), (d != 0).mean())
