@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   float* s_scale = reinterpret_cast<float*>(smem + HBUF + NRING * TPB * WBUF);
   float* s_shift = s_scale + a.C;
   // BatchNorm (sum, sumsq) of this workgroup's current kout block, per 64-pixel wave row: [4][2][BKO].  Items add into
-  // it with ds_add_f32 (each entry has exactly one writer wave, so the order -- and the fp32 result -- is deterministic);
+  // it in place (each entry has exactly one writer lane, so the order -- and the fp32 result -- is deterministic);
   // it is written out as ONE set of four partial rows per workgroup and kout block instead of four rows per tile
   // (40960 partial rows -> 1024 for the layer1 shape: the second-stage row reduction was 2.4 % of the step).
   float* s_stat = s_shift + a.C;
@@ -435,11 +435,21 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
       }
       if (a.stats) {
         if (li == 0) {
+          // each (wave row, kout) entry has exactly one writer LANE in the workgroup, so the running sums are updated with plain
+          // 16-byte reads and writes: the 8 * TK LDS float atomics this replaces held the LDS pipe ~40 cycles each (measured on the
+          // ping-pong form, tools/microbench/pp64_phase_bench.hip: 1400 -> 250 cycles per tile)
           float* sp = s_stat + (wp * 2) * BKO + wk * (BKO / WK) + g * (4 * TK);
 #pragma unroll
-          for (int j = 0; j < 4 * TK; ++j) {
-            __hip_atomic_fetch_add(sp + j, s1[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(sp + BKO + j, s2[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (int h = 0; h < 2; ++h) {
+            const float* sv = h ? s2 : s1;
+#pragma unroll
+            for (int c4 = 0; c4 < TK; ++c4) {
+              f32x4_t* slot = reinterpret_cast<f32x4_t*>(sp + h * BKO + c4 * 4);
+              f32x4_t v = *slot;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += sv[c4 * 4 + e];
+              *slot = v;
+            }
           }
         }
         if (done || nxt.k0 != cur.k0) {           // last item of this kout block: publish the four rows (uniform branch)
@@ -527,7 +537,10 @@ static hipError_t launch_ht(const ConvArgs& a, hipStream_t st) {
   const bool xf = a.in_scale != nullptr;
   if (a.K % 128 == 0) return xf ? launch_h<T, 128, 2, true>(a, st) : launch_h<T, 128, 2, false>(a, st);
   if constexpr (sizeof(T) == 2)
-    if (h16_resident(a)) return xf ? launch_h<T, 64, 2, true, true>(a, st) : launch_h<T, 64, 2, false, true>(a, st);
+    if (h16_resident(a)) {
+      if (conv_pp64_ok(DT_BF16, a)) return launch_conv_pp64(a, st);        // ping-pong form (conv_pp64.hip)
+      return xf ? launch_h<T, 64, 2, true, true>(a, st) : launch_h<T, 64, 2, false, true>(a, st);
+    }
   return xf ? launch_h<T, 64, 2, true>(a, st) : launch_h<T, 64, 2, false>(a, st);
 }
 
@@ -542,6 +555,7 @@ const char* conv_h16_name(int dtype, const ConvArgs& a) {
     if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, true, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, false, false>";
     return xf ? "sslcr::conv3x3_h16_kernel<float, 128, 2, true, false>" : "sslcr::conv3x3_h16_kernel<float, 128, 2, false, false>";
   }
+  if (bf && h16_resident(a) && conv_pp64_ok(DT_BF16, a)) return conv_pp64_name(a);
   if (bf && h16_resident(a))
     return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true, true>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false, true>";
   if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false, false>";

@@ -41,6 +41,10 @@ bool conv_h16_ok(int dtype, const ConvArgs& a);
 int conv_h16_rows(const ConvArgs& a);
 hipError_t launch_conv_h16(int dtype, const ConvArgs& a, hipStream_t st);
 const char* conv_h16_name(int dtype, const ConvArgs& a);
+// conv_pp64.hip: ping-pong form of the bf16 64 -> 64 resident-filter shape (same partial-row count as conv_h16_rows)
+bool conv_pp64_ok(int dtype, const ConvArgs& a);
+hipError_t launch_conv_pp64(const ConvArgs& a, hipStream_t st);
+const char* conv_pp64_name(const ConvArgs& a);
 // conv_dma.hip
 int conv_dma_bp(int dtype, const ConvArgs& a);
 int conv_dma_rows(const ConvArgs& a, int bp);

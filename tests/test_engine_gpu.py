@@ -77,7 +77,8 @@ def relx(got, want):
 
 def grad_rows_check(name, dtype, names, grad_of, g, emu_key="grad_bf16emul_err"):
     """every parameter gradient against the float64 run of the same iteration: L2 norm and one seeded +-1 projection.
-    fp32: max(3e-3, 3 x the reference's own fp32 error).  bf16: 2 x the measured error of THIS parameter (floor 1e-2 for the norm;
+    fp32: max(3e-3, 3 x the reference's own fp32 error).  bf16: 2 x the measured error of THIS parameter (floor max(1e-2, 0.3 x the
+    emulated bf16-storage error) for the norm;
     a single +-1 projection of an error vector e is ~N(0, |e|^2), so its floor is the parameter's measured norm-scale error:
     3.5 sigma of the emulated bf16-storage error), never above the old 2 x / 3.5 x emulation + 0.05 rule."""
     l2_ref, pr_ref, ref_err, emu = g[f"{name}/grad_l2_f64"], g[f"{name}/grad_probe_f64"], g[f"{name}/grad_ref32_err"], g[f"{name}/{emu_key}"]
@@ -93,7 +94,9 @@ def grad_rows_check(name, dtype, names, grad_of, g, emu_key="grad_bf16emul_err")
                 tol = max(3e-3, 3.0 * ref_err[i])
                 assert e_l2 <= tol and e_pr <= tol
             else:
-                held(f"{name}/grad_l2/{i}/{dtype}", e_l2, 2.0 * emu[i] + 0.05, floor=1e-2)
+                # |g| can agree by cancellation although the vectors differ (a measured 1e-4 next to an emulated 0.4 is luck, and the
+                # next kernel change lands at 2e-2): the floor scales with the error bf16 storage alone causes for this parameter
+                held(f"{name}/grad_l2/{i}/{dtype}", e_l2, 2.0 * emu[i] + 0.05, floor=max(1e-2, 0.3 * emu[i]))
                 held(f"{name}/grad_pr/{i}/{dtype}", e_pr, 3.5 * emu[i] + 0.05, floor=max(1e-2, 1.75 * emu[i]))
         except AssertionError as ex:
             bad.append(rows[-1] + f"   <- {ex}")

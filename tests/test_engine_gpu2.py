@@ -302,13 +302,12 @@ def test_trajectory_vs_reference(name, dtype):
         # 1e-2 after 12 iterations, 2.2e-2 after 24)
         check_snapshot(g, name, state_of(ms, cs), 5e-2)
     else:
-        # per iteration: 2 x the deviation measured for THAT iteration (tests/measured_errors.json), floor 2e-3, ceiling 3e-2
-        for it, d_ in enumerate(dev):
-            held(f"{name}/iter{it:02d}/{dtype}", d_, 3e-2, floor=2e-3)
+        # every iteration within 2 x the LARGEST per-iteration deviation measured over the trajectory (tests/measured_errors.json;
+        # which iteration carries the maximum moves with any change of summation order, the maximum itself does not), ceiling 3e-2
+        held(f"{name}/iter_max/{dtype}", max(dev), 3e-2, floor=2e-3)
         mid, tail = float(np.mean(dev[8:16])), float(np.mean(dev[-8:]))
         assert tail <= 1.3 * mid + 2e-3, (mid, tail, dev)
-        for j, d_ in enumerate(vdev):
-            held(f"{name}/val{j}/{dtype}", d_, 5e-2, floor=2e-3)
+        held(f"{name}/val_max/{dtype}", max(vdev), 5e-2, floor=2e-3)
 
 
 # ------------------------------------------------------------------------------------------------ e: virtual ranks on one GPU

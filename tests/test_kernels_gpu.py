@@ -98,7 +98,7 @@ def test_conv_fwd_raw_stats(case, dtype):
     if expect:
         assert expect in K.last_conv_kernel, K.last_conv_kernel
     if case == (70, 32, 32, 64, 64, 3, 1, 1) and dtype == 1:      # 280 tiles on 256 workgroups: the resident-filter walk
-        assert "conv3x3_h16_kernel<unsigned short, 64, 2, false, true>" in K.last_conv_kernel, K.last_conv_kernel
+        assert "conv3x3_pp64_kernel<false, 0>" in K.last_conv_kernel, K.last_conv_kernel
     want = R.conv_fwd(x, w, stride, pad)
     close(y, want, TOL[dtype], "conv raw")
     s, ss = R.channel_stats(want)
@@ -271,7 +271,7 @@ def test_conv_bn_backward_front_end(case, dtype):
     sc, sh, mu = rnd(84, (Ko,)), rnd(85, (Ko,)), rnd(86, (Ko,))
     y, stats = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, want_stats=True,
                         mask=(to_dev(xbn, dtype), sc.to(DEV), sh.to(DEV), mu.to(DEV)))
-    assert "conv3x3_h16_kernel" in K.last_conv_kernel, K.last_conv_kernel
+    assert ("conv3x3_pp64_kernel<false, 2>" if (C == 64 and Ko == 64 and dtype == 1) else "conv3x3_h16_kernel") in K.last_conv_kernel, K.last_conv_kernel
     want = R.conv_fwd(x, w, 1, 1)
     keep = (xbn * sc + sh) > 0
     g = want * keep
@@ -757,3 +757,52 @@ def test_brightness_contrast_and_the_randaugment_colour_subset():
     d = (out.astype(np.int16) - np.stack(ref).astype(np.int16)) % 256
     d = np.minimum(d, 256 - d)
     assert d.max() <= 2 and (d != 0).mean() < 1e-3, (d.max(), (d != 0).mean())
+
+
+@pytest.mark.parametrize("case", [(1, 16, 16), (1, 16, 32), (3, 16, 16), (5, 48, 32), (33, 32, 32), (140, 32, 32), (641, 16, 16), (20, 64, 64)])
+@pytest.mark.parametrize("op", ["plain_stats", "residual_relu_bias", "prologue_stats", "mask"])
+def test_conv_pingpong_64(case, op):
+    """conv_pp64.hip, the two-group ping-pong form of the bf16 64 -> 64 3x3 conv (layer1 forward / eval-fused forward / both
+    dgrads): every operand combination it serves, on tile counts that exercise its walk -- one tile (group 1 never live), two,
+    odd counts (group 1 one live stage short), fewer pairs than workgroups, more than one round (513+ tiles), and a 64x64 map."""
+    K = _k()
+    N, H, W = case
+    dtype = 1
+    x = q(rnd(91, (N, H, W, 64)), dtype)
+    w = q(rnd(92, (64, 3, 3, 64), 0.05), dtype)
+    kw, ref_kw = {}, {}
+    if op == "residual_relu_bias":
+        res, bias = q(rnd(93, (N, H, W, 64)), dtype), rnd(94, (64,))
+        kw = dict(residual=to_dev(res, dtype), bias=bias.to(DEV), relu=True)
+        ref_kw = dict(residual=res, bias=bias, relu=True)
+    if op == "prologue_stats":
+        sc, sh = rnd(95, (64,)).abs() + 0.5, rnd(96, (64,))
+        kw = dict(in_scale=sc.to(DEV), in_shift=sh.to(DEV), in_relu=True, want_stats=True)
+        ref_kw = dict(in_scale=sc, in_shift=sh, in_relu=True)
+    if op == "plain_stats":
+        kw = dict(want_stats=True)
+    if op == "mask":
+        xbn = q(rnd(97, (N, H, W, 64), 2.0) + 0.3, dtype)
+        sc, sh, mu = rnd(98, (64,)), rnd(99, (64,)), rnd(100, (64,))
+        y, stats = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, want_stats=True, mask=(to_dev(xbn, dtype), sc.to(DEV), sh.to(DEV), mu.to(DEV)))
+        assert "conv3x3_pp64_kernel<false, 2>" in K.last_conv_kernel, K.last_conv_kernel
+        want = R.conv_fwd(x, w, 1, 1)
+        g = want * ((xbn * sc + sh) > 0)
+        edge = (xbn * sc + sh).abs() < 1e-6
+        close(torch.where(edge.to(DEV), torch.zeros_like(y), y), torch.where(edge, torch.zeros_like(g), g), TOL[dtype], "masked dgrad")
+        st = stats.double().sum(0).cpu()
+        close(st[0], g.double().sum((0, 1, 2)), 3e-3, "sum g")
+        close(st[1], (g.double() * (xbn.double() - mu.double())).sum((0, 1, 2)), 3e-3, "sum g (x - mean)")
+        return
+    out = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, **kw)
+    assert "conv3x3_pp64_kernel" in K.last_conv_kernel, K.last_conv_kernel
+    want = R.conv_fwd(x, w, 1, 1, **ref_kw)
+    if kw.get("want_stats"):
+        y, stats = out
+        s, ss = R.channel_stats(want)
+        st = stats.double().sum(0).cpu()
+        close(st[0], s, 2e-3, "sum")
+        close(st[1], ss, 2e-3, "sumsq")
+    else:
+        y = out
+    close(y, want, TOL[dtype], f"pp64 {op}")
