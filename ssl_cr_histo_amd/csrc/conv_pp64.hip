@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
         float f[EPC];
         Elem<T>::unpack(v, f);
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), relu_lo);
+        for (int e = 0; e < EPC; ++e) f[e] = __builtin_amdgcn_fmed3f(fmaf(f[e], sc[e], sh[e]), relu_lo, __builtin_inff());   // one clamp, no canonicalising max pair
         v = PackH<T>::run(f);
       }
       const bool ok = (hin >> i) & 1u;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
               a1[e] += gv;
               a2[e] = fmaf(gv, xr[e] - mmu[e], a2[e]);
             }
-            if (live) st16(yg + out_off(cur, p) + q * 64, PackH<T>::run(vq));
+            if (live) st16(yg + out_off(cur, p) + q * 64, PackH<T>::run(vq));      // (uniform)
           }
 #pragma unroll
           for (int e = 0; e < EPC; e += 4) {
@@ -352,30 +352,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
           for (int e = 0; e < EPC; ++e) { s1[q * EPC + e] = a1[e]; s2[q * EPC + e] = a2[e]; }
         }
       } else {
-        float bias[4 * TK];
+        // The phase is bound by its VALU instruction COUNT (a wave issues one per ~4 cycles and nothing hides them, see the
+        // header), so the two uniform cases are separate straight-line bodies: the train-mode forward has neither bias nor ReLU
+        // nor residual -- pack and store -- and the others clamp with ONE v_med3 per element instead of a branch per chunk.
+        if (live) {
+          if (OP == 0 && !a.bias && !a.relu) {
 #pragma unroll
-        for (int j = 0; j < 4 * TK; ++j) bias[j] = s_bias[kb + (j >> 3) * 32 + (j & 7)];
+            for (int p = 0; p < TP; ++p)
 #pragma unroll
-        for (int p = 0; p < TP; ++p) {
-          float v[4 * TK];
+              for (int q = 0; q < RQ; ++q) {
+                float vq[EPC];
 #pragma unroll
-          for (int t = 0; t < TK; ++t)
+                for (int e = 0; e < EPC; ++e) vq[e] = acc[(q * EPC + e) >> 2][p][e & 3];
+                st16(yg + out_off(cur, p) + q * 64, PackH<T>::run(vq));
+              }
+          } else {
+            float bias[4 * TK];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[t * 4 + j] = acc[t][p][j] + bias[t * 4 + j];
+            for (int j = 0; j < 4 * TK; ++j) bias[j] = s_bias[kb + (j >> 3) * 32 + (j & 7)];
+            const float lo = a.relu ? 0.f : -__builtin_inff();
 #pragma unroll
-          for (int q = 0; q < RQ; ++q) {
-            float* vq = v + q * EPC;
-            if constexpr (OP == 1) {
-              float rr[EPC];
-              Elem<T>::unpack(rres[RPRE ? p : 0][RPRE ? q : 0], rr);
+            for (int p = 0; p < TP; ++p)
 #pragma unroll
-              for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
-            }
-            if (a.relu) {
+              for (int q = 0; q < RQ; ++q) {
+                float vq[EPC], rr[EPC];
+                if constexpr (OP == 1) Elem<T>::unpack(rres[RPRE ? p : 0][RPRE ? q : 0], rr);
 #pragma unroll
-              for (int e = 0; e < EPC; ++e) vq[e] = fmaxf(vq[e], 0.f);
-            }
-            if (live) st16(yg + out_off(cur, p) + q * 64, PackH<T>::run(vq));
+                for (int e = 0; e < EPC; ++e) {
+                  float v = acc[(q * EPC + e) >> 2][p][e & 3] + bias[q * EPC + e];
+                  if constexpr (OP == 1) v += rr[e];
+                  vq[e] = __builtin_amdgcn_fmed3f(v, lo, __builtin_inff());
+                }
+                st16(yg + out_off(cur, p) + q * 64, PackH<T>::run(vq));
+              }
           }
         }
         if (a.stats) {
