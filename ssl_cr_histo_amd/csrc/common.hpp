@@ -97,6 +97,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// clamps as ONE v_med3_f32: fmaxf(x, 0) compiles to a canonicalising v_max x, x followed by the max, and in the output stages of
+// the conv kernels every VALU instruction is ~4 exposed cycles (tools/microbench/pp64_phase_bench.hip)
+__device__ __forceinline__ float clamp_lo(float x, float lo) { return __builtin_amdgcn_fmed3f(x, lo, __builtin_inff()); }
+__device__ __forceinline__ float relu0(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+
 __device__ __forceinline__ u32x4_t ld16(const void* p) { return *reinterpret_cast<const u32x4_t*>(p); }
 __device__ __forceinline__ void st16(void* p, const u32x4_t& v) { *reinterpret_cast<u32x4_t*>(p) = v; }
 // streaming (non-temporal) forms for the read-once / write-once tensors of the HBM-bound elementwise kernels
@@ -164,7 +169,7 @@ __device__ __forceinline__ void conv_store_tile_t(const f32x4_t (&acc)[TK][TP], 
       }
       if constexpr (RELU) {
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) vq[e] = fmaxf(vq[e], 0.f);
+        for (int e = 0; e < EPC; ++e) vq[e] = relu0(vq[e]);
       }
       if (ok[p]) st16(yg + off[p] + q * 16, PackH<T>::run(vq));
     }

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
       float f[EPC];
       Elem<T>::unpack(v, f);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) f[e] = fmaxf(fmaf(f[e], sc[e], sh[e]), relu_lo);
+      for (int e = 0; e < EPC; ++e) f[e] = clamp_lo(fmaf(f[e], sc[e], sh[e]), relu_lo);
       v = PackH<T>::run(f);
     }
     const bool ok = (hin >> i) & 1u;
