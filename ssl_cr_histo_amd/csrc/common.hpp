@@ -89,6 +89,31 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
   return v;
 }
+// Sum over the 16 lanes of a DPP row, four values at a time, with the lane permutation folded into the add (v_add_f32_dpp): 16
+// instructions per four values where row16_sum() (a v_mov_b32_dpp + an add per step) takes 32.  Interleaving the four keeps three
+// instructions between a register's write and its next DPP read (the hardware wants two wait states); the leading s_nop covers the
+// compiler's instruction in front of the block.
+__device__ __forceinline__ void row16_sum4(float& a, float& b, float& c, float& d) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
+      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 // full 64-lane sum, result valid in every lane
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);

@@ -51,31 +51,6 @@ __device__ unsigned long long g_pp_prof[8][8];
 // segment per store instruction (the layout of conv_h16 -- 16 consecutive kouts per lane -- makes every 16-byte store half of a
 // 32-byte stride: twice the write requests, and the output stage is bound by exactly their issue rate).
 #define PP_CH(t, g, j) ((((t) >> 1) * 32) + ((g) * 8) + (((t) & 1) * 4) + (j))
-// Sum over the 16 lanes of a DPP row, four values at a time, with the lane permutation folded into the add (v_add_f32_dpp): 16
-// instructions per four values where row16_sum() (a v_mov_b32_dpp + an add per step) takes 32.  Interleaving the four keeps three
-// instructions between a register's write and its next DPP read (the hardware wants two wait states); the leading s_nop covers the
-// compiler's instruction in front of the block.
-__device__ __forceinline__ void row16_sum4(float& a, float& b, float& c, float& d) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-      "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
-      : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-}
 // LDS row of the resident filter bank -> kout row: fragment row 4g + j of tile t feeds accumulator (t, g, j)
 __device__ __forceinline__ int pp_row_kout(int rr) {
   const int t = rr >> 4, gq = (rr >> 2) & 3, j = rr & 3;
