@@ -149,50 +149,99 @@ def test_fp8_camelyon_full_size_step_vs_reference():
     assert torch.equal(ret[5].cpu(), torch.from_numpy(g[f"{name}/targets"]))
 
 
-def test_fp8_config5_per_gpu_shape_vs_parity_engine():
-    """BASELINE config 5's per-GPU shape (--batch_size 1024 over 8 GPUs: two class loaders x 128 x 3 labeled = 768, 2 x 896 = 1792
-    unlabeled -> student 2560 / teacher 1792 images of 256x256, 4352 distinct patches): ONE step in the fp8 engine mode against the
-    same step in the fp32 exact-parity mode (which holds 1e-3 against the reference goldens at 640 / 448 images).  Reports and
-    bounds the fp8 error on losses, logits and the classifier gradient at the size the configuration names."""
-    from test_engine_gpu import build, freeze
-    from ssl_cr_histo_amd import engine as E
+# ------------------------------------------------------------------------------------------------ config 5 at its own shape vs the oracle
+_C5 = {}
+
+
+def _config5_oracle():
+    """ONE eval_Camelyon_SSL_CR.train iteration at BASELINE config 5's per-GPU shape (student 768 + 1792 = 2560, teacher 1792 images
+    of 256x256) on the CPU oracle (oracle/steps.py:ssl_cr_step, one backbone pass per image).  The reference's own train() cannot
+    produce this golden in the build container: TripletNet_Finetune runs the backbone three times on the 2560-image batch and
+    autograd keeps ~30 MB per image-pass (~230 GB; the container has 64 GB) -- so the fixture is the oracle, which tests/
+    test_oracle_golden.py pins to the reference's functions at every size that does fit, run here on the GPU box's host
+    (3 TB, 256 cores; ~1-2 minutes at 32 threads).  Skipped when the host has less than 256 GB available."""
+    if _C5:
+        return _C5
+    avail = 0
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            avail = int(line.split()[1]) // (1 << 20)
+    if avail < 256:
+        pytest.skip(f"config-5 oracle needs ~150 GB of host memory, {avail} GB available")
+    import os
+    from collections import OrderedDict
+    from oracle import model as OM, steps as S
     hw, b, mu = 256, 128, 7
     nx, nu = 2 * b * 3, 2 * b * mu
-    x = C.u8(9100, (nx, 3, hw, hw)).to(DEV)
-    u_w, u_s = C.u8(9101, (nu, 3, hw, hw)).to(DEV), C.u8(9102, (nu, 3, hw, hw)).to(DEV)
-    y = C.ints(9103, (nx,), 2).to(DEV)
-    out = {}
-    for dtype in ("fp32", "fp8"):
-        eng = E.Engine(DEV, dtype)
-        mt, ct = build("finetune", "finetune", 2, True)
-        ms, cs = build("finetune", "finetune", 2, True)
-        OMs = {k: v.clone() for k, v in ms.state_dict().items()}
-        freeze(mt, 64)
-        mt.eval(); ms.train()
-        te, st = eng.bind(mt, ct), eng.bind(ms, cs)
-        if dtype == "fp8":         # delayed scaling: the first forward of a net runs at scale 1 and records amax; scales follow from the second on
-            eng.step_ssl_cr(te, st, "ce", x, y, u_w, u_s, 1.0, backward=False)
-            ms.load_state_dict(OMs)                    # undo the warm-up's running-statistics update: same starting state as the fp32 run
-        r = eng.step_ssl_cr(te, st, "ce", x, y, u_w, u_s, 1.0)
-        torch.cuda.synchronize()
-        out[dtype] = dict(losses=r["losses"].cpu().double(), logits=r["logits"].cpu().double(), logits_t=r["logits_t"].cpu().double(),
-                          gcls=st.grad(64).cpu().double(), gfc=st.grad(60).cpu().double())
-        del eng, te, st, mt, ms
-        torch.cuda.empty_cache()
-    a, bq = out["fp32"], out["fp8"]
-    dl = ((bq["losses"][:3] - a["losses"][:3]).abs() / a["losses"][:3].abs()).tolist()
-    e_log = float((bq["logits"] - a["logits"]).norm() / a["logits"].norm())
-    e_logt = float((bq["logits_t"] - a["logits_t"]).norm() / a["logits_t"].norm())
-    e_g = float((bq["gcls"] - a["gcls"]).norm() / a["gcls"].norm())
-    e_fc = float((bq["gfc"] - a["gfc"]).norm() / a["gfc"].norm())
-    flips = int(((bq["logits_t"].argmax(1)) != (a["logits_t"].argmax(1))).sum())
-    print(f"[fp8 vs fp32 engine, student {nx + nu} / teacher {nu}] loss deviations {dl}; logits rel L2 {e_log:.3e} (teacher {e_logt:.3e}); "
-          f"pseudo-label flips {flips}/{nu}; classifier gradient rel L2 {e_g:.3e}, fc.0 gradient {e_fc:.3e}")
-    # 2 x the deviations measured on the MI355X (tests/measured_errors.json); the constants are ceilings
-    for i, d_ in enumerate(dl):
-        held(f"config5/loss{i}/fp8_vs_fp32", d_, 6e-2, floor=1e-3)
-    held("config5/logits/fp8_vs_fp32", e_log, 0.3, floor=1e-2)
-    held("config5/logits_t/fp8_vs_fp32", e_logt, 0.3, floor=1e-2)
-    held("config5/grad_classifier/fp8_vs_fp32", e_g, 0.5, floor=1e-2)
-    held("config5/grad_fc0/fp8_vs_fp32", e_fc, 0.5, floor=1e-2)
-    assert flips <= max(2, nu // 200), flips
+    x, u_w, u_s = C.u8(9100, (nx, 3, hw, hw)), C.u8(9101, (nu, 3, hw, hw)), C.u8(9102, (nu, 3, hw, hw))
+    y = C.ints(9103, (nx,), 2)
+
+    def state():
+        p, bufs = OM.split_state(OM.init_state(C.PARAM_SEED, OM.net_param_specs(), random_running_stats=True))
+        pc, _ = OM.split_state(OM.init_state(C.PARAM_SEED + 1, OM.classifier_param_specs("finetune", 2)))
+        p = OrderedDict(p)
+        p.update(pc)
+        return p, bufs
+    ps, bs = state()
+    pt, bt = state()
+    for v in ps.values():
+        v.requires_grad_(True)
+
+    class KeepGrads:                       # an "optimizer" that only lets the step run its backward
+        def zero_grad(self):
+            pass
+
+        def step(self):
+            pass
+    threads = torch.get_num_threads()
+    torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    try:
+        o = S.ssl_cr_step("ce", ps, bs, pt, bt, KeepGrads(), x.float(), y, u_w.float(), u_s.float(), 1.0, faithful=False)
+    finally:
+        torch.set_num_threads(threads)
+    names = list(ps.keys())
+    _C5.update(x=x, y=y, u_w=u_w, u_s=u_s, loss=(o["loss"], o["loss_x"], o["loss_u"]), acc=o["acc"],
+               logits=torch.cat((o["logits_x"], o["logits_u_s"])).double(), logits_t=o["logits_u_w"].double(),
+               grads={k: ps[k].grad.double() for k in ("fc.0.weight", "classifier.0.weight", "model.layer4.1.conv2.weight",
+                                                       "model.layer2.0.conv1.weight")},
+               index={k: names.index(k) for k in names})
+    return _C5
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_config5_per_gpu_shape_vs_oracle(dtype):
+    """BASELINE config 5 (eval_Camelyon_SSL_CR.py:94-121 at --batch_size 1024 over 8 GPUs) at its own per-GPU shape, in the bf16
+    engine mode and in the fp8 mode (e4m3 forward convs of layers 2-4), against the CPU oracle's iteration on the same inputs:
+    losses, student / teacher logits, pseudo-label flips, and the gradients of four parameters from the head down to layer2.
+    Bounds = 2 x the deviations measured on the MI355X (tests/measured_errors.json); the constants are ceilings."""
+    from test_engine_gpu import build, freeze
+    from ssl_cr_histo_amd import engine as E
+    g = _config5_oracle()
+    x, y, u_w, u_s = (g[k].to(DEV) for k in ("x", "y", "u_w", "u_s"))
+    eng = E.Engine(DEV, dtype)
+    mt, ct = build("finetune", "finetune", 2, True)
+    ms, cs = build("finetune", "finetune", 2, True)
+    state0 = {k: v.clone() for k, v in ms.state_dict().items()}
+    freeze(mt, 64)
+    mt.eval(); ms.train()
+    te, st = eng.bind(mt, ct), eng.bind(ms, cs)
+    if dtype == "fp8":          # delayed scaling: the first forward calibrates; undo its running-statistics update
+        eng.step_ssl_cr(te, st, "ce", x, y, u_w, u_s, 1.0, backward=False)
+        ms.load_state_dict(state0)
+    r = eng.step_ssl_cr(te, st, "ce", x, y, u_w, u_s, 1.0)
+    torch.cuda.synchronize()
+    got = r["losses"].cpu().double()
+    tag = f"config5_oracle/{dtype}"
+    for i, nm in enumerate(("loss", "loss_x", "loss_u")):
+        held(f"{tag}/{nm}", abs(float(got[i]) - g["loss"][i]) / abs(g["loss"][i]), 6e-2, floor=1e-3)
+    lg, lt = r["logits"].cpu().double(), r["logits_t"].cpu().double()
+    held(f"{tag}/logits", float((lg - g["logits"]).norm() / g["logits"].norm()), 0.3, floor=1e-2)
+    held(f"{tag}/logits_t", float((lt - g["logits_t"]).norm() / g["logits_t"].norm()), 0.3, floor=1e-2)
+    flips = int((lt.argmax(1) != g["logits_t"].argmax(1)).sum())
+    assert flips <= max(2, lt.shape[0] // 200), flips
+    assert abs(float(got[3]) / x.shape[0] - g["acc"]) <= 3.0 / x.shape[0]
+    for k, want in g["grads"].items():
+        mine = st.grad(g["index"][k]).cpu().double()
+        held(f"{tag}/grad/{k}", float((mine - want).norm() / want.norm()), 0.9, floor=2e-2)
+    del eng, te, st
+    torch.cuda.empty_cache()
