@@ -153,7 +153,7 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // `if (residual) load` inside the store loop, the compiler put an s_waitcnt vmcnt(0) in front of every store -- also when
 // the loads were skipped -- and vmcnt retires in order, so each 16-byte store waited out the full write round trip of the
 // one before it (conv_dma: a quarter of the kernel; ISA: store, load, vmcnt(0), store, ...).
-template <typename T, int TK, int TP, bool RES, bool ACC, bool RELU>
+template <typename T, int TK, int TP, bool RES, bool ACC, bool RELU, bool BIAS = true>
 __device__ __forceinline__ void conv_store_tile_t(const f32x4_t (&acc)[TK][TP], const float (&bias)[4 * TK], const size_t (&off)[TP],
                                                   const bool (&ok)[TP], char* yg, const char* rg) {
   constexpr int EPC = Elem<T>::EPC, RQ = 4 * TK / EPC;
@@ -176,7 +176,7 @@ __device__ __forceinline__ void conv_store_tile_t(const f32x4_t (&acc)[TK][TP], 
 #pragma unroll
     for (int t = 0; t < TK; ++t)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[t * 4 + j] = acc[t][p][j] + bias[t * 4 + j];
+      for (int j = 0; j < 4; ++j) v[t * 4 + j] = BIAS ? acc[t][p][j] + bias[t * 4 + j] : acc[t][p][j];
 #pragma unroll
     for (int q = 0; q < RQ; ++q) {
       float* vq = v + q * EPC;
@@ -211,6 +211,14 @@ __device__ __forceinline__ void conv_store_tile(const f32x4_t (&acc)[TK][TP], co
     if (accumulate) { if (relu) conv_store_tile_t<T, TK, TP, false, true, true>(acc, bias, off, ok, yg, rg); else conv_store_tile_t<T, TK, TP, false, true, false>(acc, bias, off, ok, yg, rg); }
     else { if (relu) conv_store_tile_t<T, TK, TP, false, false, true>(acc, bias, off, ok, yg, rg); else conv_store_tile_t<T, TK, TP, false, false, false>(acc, bias, off, ok, yg, rg); }
   }
+}
+// the same with the caller's knowledge that there is no bias (train-mode forward, every dgrad): the plain body is pack + store
+template <typename T, int TK, int TP>
+__device__ __forceinline__ void conv_store_tile_nobias(const f32x4_t (&acc)[TK][TP], const float (&bias)[4 * TK], const size_t (&off)[TP],
+                                                       const bool (&ok)[TP], char* yg, const char* rg, bool accumulate, bool relu) {
+  if (!rg && !accumulate && !relu) conv_store_tile_t<T, TK, TP, false, false, false, false>(acc, bias, off, ok, yg, rg);
+  else if (rg && !accumulate && !relu) conv_store_tile_t<T, TK, TP, true, false, false, false>(acc, bias, off, ok, yg, rg);
+  else conv_store_tile<T, TK, TP>(acc, bias, off, ok, yg, rg, accumulate, relu);
 }
 
 }  // namespace sslcr

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     const size_t opix = ((size_t)n * a.OH + (size_t)ph * a.osh) * a.OW + (size_t)pw * a.osh;
     off[p] = (opix * a.K + kb) * sizeof(T);
   }
-  conv_store_tile<T, TK, TP>(acc, bias, off, ok, yg, rg, a.accumulate != 0, a.relu != 0);
+  if (a.bias) conv_store_tile<T, TK, TP>(acc, bias, off, ok, yg, rg, a.accumulate != 0, a.relu != 0);
+  else conv_store_tile_nobias<T, TK, TP>(acc, bias, off, ok, yg, rg, a.accumulate != 0, a.relu != 0);
 
   if (a.stats) {
     // rows >= M were staged as zeros -> contribute 0.  Sum over this wave's 64 pixels.
@@ -219,9 +220,14 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
         float x1 = 0.f, x2 = 0.f;
 #pragma unroll
         for (int p = 0; p < TP; ++p) { float q = acc[t][p][j]; x1 += q; x2 = fmaf(q, q, x2); }
-        s1[t * 4 + j] = row16_sum(x1);
-        s2[t * 4 + j] = row16_sum(x2);
+        s1[t * 4 + j] = x1;
+        s2[t * 4 + j] = x2;
       }
+#pragma unroll
+    for (int j = 0; j < 4 * TK; j += 4) {        // DPP folded into the adds: half the instructions of row16_sum()
+      row16_sum4(s1[j], s1[j + 1], s1[j + 2], s1[j + 3]);
+      row16_sum4(s2[j], s2[j + 1], s2[j + 2], s2[j + 3]);
+    }
     if (li == 0) {
       float* sp = a.stats + ((size_t)(blockIdx.x * WP + wp) * 2) * a.K + kb;
 #pragma unroll

@@ -265,6 +265,22 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
 #pragma unroll
         for (int q = 0; q < 16 / EPC; ++q) st16(yp + STEM_CH((q * EPC) >> 2, g, 0) * sizeof(T), PackH<T>::run(v + q * EPC));
       }
+    } else if (ho0 + TH <= a.OH && wo0 + TW <= a.OW && a.bias && a.relu && !a.stats) {
+      // the eval-mode (teacher / validate) case -- full tile, folded-BatchNorm bias, ReLU, no statistics: add, one v_med3 clamp,
+      // pack, store; the general path below spends a select, two statistics updates and a second max per element on it
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int ho = ho0 + 2 * wave + p, wo = wo0 + li;
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[t * 4 + j] = relu0(acc[t][p][j] + bias[t * 4 + j]);
+        char* yp = reinterpret_cast<char*>(a.y) + ((((size_t)n * a.OH + ho) * a.OW + wo) * 64) * sizeof(T);
+        constexpr int EPC = Elem<T>::EPC;
+#pragma unroll
+        for (int q = 0; q < 16 / EPC; ++q) st16(yp + STEM_CH((q * EPC) >> 2, g, 0) * sizeof(T), PackH<T>::run(v + q * EPC));
+      }
     } else
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
