@@ -55,6 +55,18 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define SSLCR_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0f70) /* vmcnt(0), lgkmcnt/expcnt untouched */
 
+// phase timing for tools/microbench/h16_phase_bench.hip (-DSSLCR_H16_PROF; compiled out otherwise): per wave of workgroup 0, shader
+// cycles of a stage spent waiting for the weight DMA, at the publish (P) and free (F) barriers, in the stage-end halo swap and in
+// the item epilogue
+#ifdef SSLCR_H16_PROF
+__device__ unsigned long long g_h16_prof[16][8];
+#define H16_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define H16_ACC(i, d) h16_t[i] += (d)
+#else
+#define H16_T(v)
+#define H16_ACC(i, d)
+#endif
+
 // XF: the producer's BatchNorm(+ReLU) is applied to the input on its way into LDS (a.in_scale != nullptr)
 // WR: the whole filter bank stays resident in LDS (C == one slab and K == BKO, i.e. the 64->64 layer1 convs: 9 x 64 x 128 B
 //     = 72 KB next to the 54 KB halo).  A stage then has no weight DMA, no publish/free barriers and no vmcnt wait before its
@@ -270,6 +282,10 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
     return ((((size_t)q.n0 * a.H + h) * a.W + w) * a.K + q.k0 + wk * (BKO / WK) + g * (4 * TK)) * sizeof(T);
   };
   int wb = 0, item = first, slab = 0;
+#ifdef SSLCR_H16_PROF
+  unsigned long long h16_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long h16_begin = __builtin_readcyclecounter();
+#endif
   for (;;) {
     // the stage after this one: next slab of this tile, or slab 0 of the next item (the last stage of the walk re-requests
     // itself: branch-free, and nobody reads what it stages)
@@ -334,8 +350,12 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
         __builtin_amdgcn_sched_barrier(0);
       }
       if (!WR && i % 6 == 2) {
+        H16_T(tp0);
         SSLCR_WAIT_VM0();
+        H16_T(tp1);
         __syncthreads();                                  // P
+        H16_T(tp2);
+        H16_ACC(0, tp1 - tp0); H16_ACC(1, tp2 - tp1);
         if (i == 8) {
           load_res();
           load_halo(nxt, nslab);
@@ -344,18 +364,25 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
         __builtin_amdgcn_sched_barrier(0);
       }
       if (!WR && (i == 5 || i == 11)) {
+        H16_T(tf0);
         __syncthreads();                                  // F
+        H16_T(tf1);
+        H16_ACC(2, tf1 - tf0);
         if (i == 5) dma_w(cur.k0, slab, 6, wb); else dma_w(nxt.k0, nslab, 0, wb ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    H16_T(ts0);
     __syncthreads();                          // every wave is done with this stage's halo
     store_halo();
     __syncthreads();
+    H16_T(ts1);
+    H16_ACC(3, ts1 - ts0); H16_ACC(5, 1);
     wb ^= 1;
     frags(0, 0, WR ? s_w : s_w + wb * (TPB * WBUF));      // first fragments of the next stage: in flight under the epilogue
     __builtin_amdgcn_sched_barrier(0);
 
+    H16_T(te0);
     if (last) {
       // ---------------- epilogue of the finished item; its stores drain under the next item's taps
       const int kb = cur.k0 + wk * (BKO / WK) + g * (4 * TK);
@@ -462,6 +489,9 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
           __syncthreads();
         }
       }
+#ifdef SSLCR_H16_PROF
+      { H16_T(te1); H16_ACC(4, te1 - te0); }
+#endif
       if (done) break;
 #pragma unroll
       for (int t = 0; t < TK; ++t)
@@ -472,6 +502,12 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
     }
     slab = nslab;
   }
+#ifdef SSLCR_H16_PROF
+  if (blockIdx.x == 0 && lane == 0) {
+    h16_t[6] = __builtin_readcyclecounter() - h16_begin;
+    for (int i = 0; i < 8; ++i) g_h16_prof[wave][i] = h16_t[i];
+  }
+#endif
   if (a.stats) {
     const int kb_first = first / tiles_total, kb_last = item / tiles_total;      // item = the last one processed
     for (int kbi = 0; kbi < a.K / BKO; ++kbi) {
