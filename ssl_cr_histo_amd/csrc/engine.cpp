@@ -181,6 +181,11 @@ struct sslcr_ctx {
   DevBuf small;       // bn stage/sums, unit scale/shift
   double* bn_stage = nullptr;
   double* bn_sums = nullptr;
+  // BatchNorm-backward sums: every reduce pass of one backward takes its own pre-zeroed [2][2][512]-double slot of this ring, and ONE
+  // memset per backward clears them all (a memset per BatchNorm was 13 launches of ~4.7 us per SSL_CR step, 46 per RSP step)
+  DevBuf bn_ring;
+  int bn_ring_i = 0;
+  static constexpr int kBnRing = 96, kBnSlot = 2 * 2 * 512;
   float *ones = nullptr, *zeros = nullptr;
   size_t esz() const { return dtype == DT_BF16 ? 2 : 4; }
 };
@@ -827,9 +832,15 @@ struct PoolSrc {            // gradient arriving through the stem max-pool (see 
 
 // BatchNorm backward in three parts so that independent BatchNorms (a block's bn2 and its projection-shortcut BatchNorm) can
 // share ONE all-reduce of their sums: begin = the reduce pass into `sums` ([2][C] doubles), sync = the all-reduce, end = the apply pass
+// the next pre-zeroed sums slot of this backward (nullptr when the ring is used up: the caller's buffer is then zeroed by a memset)
+double* take_sums(sslcr_ctx* c) {
+  if (!c->bn_ring.p || c->bn_ring_i >= sslcr_ctx::kBnRing) return nullptr;
+  return (double*)c->bn_ring.p + (size_t)(c->bn_ring_i++) * sslcr_ctx::kBnSlot;
+}
+
 int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
                  void* dx, void* gout, size_t pixels, double count, hipStream_t st, double* sums, BnBwdArgs* out, const PoolSrc* pool = nullptr,
-                 int g_in_reduce = 0, const float* sum_rows = nullptr, int n_sum_rows = 0) {
+                 int g_in_reduce = 0, const float* sum_rows = nullptr, int n_sum_rows = 0, bool sums_zeroed = false) {
   sslcr_ctx* c = n->ctx;
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
@@ -853,7 +864,7 @@ int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy,
     r.partials = sum_rows; r.rows = n_sum_rows; r.C = bn.C; r.stage = c->bn_stage; r.sums_out = sums;
     TRY(launch_bn_finalize(r, st));
   } else {
-    TRY(hipMemsetAsync(sums, 0, 2 * bn.C * sizeof(double), st));
+    if (!sums_zeroed) TRY(hipMemsetAsync(sums, 0, 2 * bn.C * sizeof(double), st));
     TRY(launch_bn_bwd_reduce(c->dtype, a, st));
   }
   *out = a;
@@ -893,8 +904,10 @@ int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, 
                 const float* sum_rows = nullptr, int n_sum_rows = 0) {
   sslcr_ctx* c = n->ctx;
   BnBwdArgs a;
-  TRYI(bn_bwd_begin(n, bn, sv, dy, x, yact, relu_from_x, dx, gout, pixels, count, st, c->bn_sums, &a, pool, g_in_reduce, sum_rows, n_sum_rows));
-  TRYI(bn_bwd_sync(c, c->bn_sums, 2 * (size_t)bn.C, st));
+  double* ring = sum_rows ? nullptr : take_sums(c);
+  double* sums = ring ? ring : c->bn_sums;
+  TRYI(bn_bwd_begin(n, bn, sv, dy, x, yact, relu_from_x, dx, gout, pixels, count, st, sums, &a, pool, g_in_reduce, sum_rows, n_sum_rows, ring != nullptr));
+  TRYI(bn_bwd_sync(c, sums, 2 * (size_t)bn.C, st));
   return bn_bwd_end(c, a, st);
 }
 
@@ -1032,10 +1045,14 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       // BatchNorms' sums ([2][C] each, adjacent in bn_sums) in ONE all-reduce before the two apply passes
       if (B.has_ds) {
         BnBwdArgs a2, ad;
-        double* sums_d = c->bn_sums + 2 * B.b2.C;
-        TRYI(bn_bwd_begin(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, c->bn_sums, &a2, nullptr, 1));
-        TRYI(bn_bwd_begin(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st, sums_d, &ad));
-        TRYI(bn_bwd_sync(c, c->bn_sums, 4 * (size_t)B.b2.C, st));
+        double* ring = take_sums(c);
+        double* sums_2 = ring ? ring : c->bn_sums;
+        double* sums_d = sums_2 + 2 * B.b2.C;
+        TRYI(bn_bwd_begin(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, sums_2, &a2, nullptr, 1,
+                          nullptr, 0, ring != nullptr));
+        TRYI(bn_bwd_begin(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st, sums_d, &ad, nullptr, 0,
+                          nullptr, 0, ring != nullptr));
+        TRYI(bn_bwd_sync(c, sums_2, 4 * (size_t)B.b2.C, st));
         TRYI(bn_bwd_end(c, a2, st));
         TRYI(bn_bwd_end(c, ad, st));
       } else {
@@ -1147,8 +1164,11 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
         // conv1 wgrad derives its dY tiles from the pooled gradient itself: the apply pass and its 2 x (N x 128 x 128 x 64)
         // round trip through HBM are gone (sslcr_stem_wgrad_pool)
         BnBwdArgs a;
-        TRYI(bn_bwd_begin(n, n->bn0, ps.bn[0], nullptr, ps.raw0, nullptr, 1, nullptr, nullptr, spix, (double)spix, st, c->bn_sums, &a, &pool));
-        TRYI(bn_bwd_sync(c, c->bn_sums, 2 * 64, st));
+        double* ring = take_sums(c);
+        double* sums0 = ring ? ring : c->bn_sums;
+        TRYI(bn_bwd_begin(n, n->bn0, ps.bn[0], nullptr, ps.raw0, nullptr, 1, nullptr, nullptr, spix, (double)spix, st, sums0, &a, &pool, 0, nullptr, 0,
+                          ring != nullptr));
+        TRYI(bn_bwd_sync(c, sums0, 2 * 64, st));
         w.dy = nullptr;
         if (c->prof.on) {
           ProfRec r;
@@ -1220,6 +1240,11 @@ int net_backward(sslcr_net* n, const float* dlogits, hipStream_t st) {
   TRYI(n->grads.ensure(n->grad_count * sizeof(float)));
   TRY(hipMemsetAsync(n->grads.p, 0, n->grad_count * sizeof(float), st));
   const bool bb = lowest_trainable(n) < 60;
+  if (bb) {
+    TRYI(c->bn_ring.ensure((size_t)sslcr_ctx::kBnRing * sslcr_ctx::kBnSlot * sizeof(double)));
+    TRY(hipMemsetAsync(c->bn_ring.p, 0, (size_t)sslcr_ctx::kBnRing * sslcr_ctx::kBnSlot * sizeof(double), st));
+    c->bn_ring_i = 0;
+  }
   TRYI(heads_backward(n, dlogits, npass, N, bb, st));
   TRYI(launch_bucket_allreduce(n, 0, n->goff[60], n->goff[n->nparams], st));
   if (bb) {
@@ -1277,7 +1302,7 @@ int sslcr_destroy(sslcr_ctx* c) {
     for (int i = 0; i < 8; ++i) (void)hipEventDestroy(c->ev_ready[i]);
     (void)hipEventDestroy(c->ev_done);
   }
-  c->scratch.release(); c->partials.release(); c->small.release();
+  c->scratch.release(); c->partials.release(); c->small.release(); c->bn_ring.release();
   delete c;
   return 0;
 }
