@@ -446,6 +446,7 @@ static int pp64_grid(const ConvArgs& a) {
 bool conv_pp64_ok(int dtype, const ConvArgs& a) {
   static const bool on = [] { const char* e = getenv("SSLCR_PP64"); return !e || atoi(e) != 0; }();
   if ((size_t)a.N * a.H * a.W * 64 * 2 >= ((size_t)1 << 32)) return false;       // the kernel addresses with 32-bit byte offsets
+  if (a.W > 2048) return false;                                                  // halo roles pack a pixel offset of up to 17 W + 17 into 16 bits
   return on && dtype == DT_BF16 && a.C == 64 && a.K == 64 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && !a.transposed &&
          a.H % 16 == 0 && a.W % 16 == 0 && !(a.in_scale && (a.residual || a.mask_x));
 }
