@@ -796,6 +796,26 @@ def gen_stages(out):
             out["stages/train/nbt"] = np.int64(sd["model.bn1.num_batches_tracked"].item())
 
 
+def gen_fwd_full(out):
+    """BASELINE config 2: the reference's TripletNet_Finetune.forward (models/net.py:86-103) on N = 256 images of 256x256, eval mode
+    (what the teacher and validate() run) and train mode (batch statistics, x3 running-stat replay): reductions of the [256, 768]
+    feature matrix + its first rows + the running statistics of four BatchNorms."""
+    x = C.u8(5100, (256, 3, 256, 256)).float()
+    for mode in ("eval", "train"):
+        model, _ = build("finetune", "finetune", 1, rand_stats=True)
+        model.train(mode == "train")
+        with torch.no_grad():
+            feats = model(x).double()
+        out[f"fwd_full/{mode}/feats_rowl2"] = feats.norm(dim=1).numpy()
+        out[f"fwd_full/{mode}/feats_colsum"] = feats.sum(0).numpy()
+        out[f"fwd_full/{mode}/feats_head"] = feats[:4].float().numpy()
+        if mode == "train":
+            sd = model.state_dict()
+            for k in ("model.bn1.running_mean", "model.bn1.running_var", "model.layer3.0.downsample.1.running_mean",
+                      "model.layer4.1.bn2.running_var"):
+                out[f"fwd_full/train/{k}"] = sd[k].numpy().copy()
+
+
 def main():
     gens = {"bpq_cr_f60": gen_bpq_cr, "bpq_cr_f0": gen_bpq_cr, "cam_cr_f60": gen_cam_cr, "cam_cr_f0": gen_cam_cr,
             "kather_cr_f0": gen_kather_cr, "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup,
@@ -815,6 +835,11 @@ def main():
         gen_stages(out)
         np.savez_compressed(os.path.join(HERE, "stages.npz"), **out)
         print("wrote stages")
+    if not only or "fwd_full" in only:
+        out = {}
+        gen_fwd_full(out)
+        np.savez_compressed(os.path.join(HERE, "fwd_full.npz"), **out)
+        print("wrote fwd_full")
 
 
 if __name__ == "__main__":

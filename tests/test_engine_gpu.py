@@ -136,6 +136,31 @@ def test_backbone_forward_vs_reference_stages(mode, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_forward_only_config2_full_size_vs_reference(mode, dtype):
+    """BASELINE config 2 at its own size -- ResNet18 forward-only, N = 256 images of 256x256 -- against reductions of the reference
+    module's own output (tests/golden/make_golden.py:gen_fwd_full): eval mode (BatchNorm folded into the conv packs, the teacher /
+    validate() path) and train mode (batch statistics, x3 running-stat replay).  fp32: 1e-3; bf16: 2 x the measured error."""
+    _engine(dtype)
+    g = load_golden("fwd_full")
+    model, _ = build("finetune", "finetune", 1, True)
+    model.train(mode == "train")
+    x = C.u8(5100, (256, 3, 256, 256)).to(DEV)
+    feats = model(x)
+    torch.cuda.synchronize()
+    f = feats.cpu().double()
+    assert tuple(f.shape) == (256, 768)
+    near(f"fwd_full/{mode}/feats_rowl2", dtype, rel_err(f.norm(dim=1), g[f"fwd_full/{mode}/feats_rowl2"]), 1e-3, 6e-2)
+    near(f"fwd_full/{mode}/feats_colsum", dtype, rel_err(f.sum(0), g[f"fwd_full/{mode}/feats_colsum"]), 1e-3, 6e-2)
+    near(f"fwd_full/{mode}/feats_head", dtype, rel_err(feats[:4].cpu(), g[f"fwd_full/{mode}/feats_head"]), 1e-3, 6e-2)
+    if mode == "train":
+        sd = model.state_dict()
+        for k in ("model.bn1.running_mean", "model.bn1.running_var", "model.layer3.0.downsample.1.running_mean",
+                  "model.layer4.1.bn2.running_var"):
+            near(f"fwd_full/train/{k}", dtype, rel_err(sd[k].cpu(), g[f"fwd_full/train/{k}"]), 1e-4, 2e-2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", ["bpq_cr_f60", "bpq_cr_f0"])
 def test_bpq_cr_epoch_vs_reference(name, dtype):
     from ssl_cr_histo_amd import steps

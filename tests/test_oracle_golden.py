@@ -184,6 +184,19 @@ def test_stage_activations(mode):
         assert int(bn2["model.bn1.num_batches_tracked"]) == int(g["stages/train/nbt"]) == 3
 
 
+def test_forward_only_config2_full_size():
+    """BASELINE config 2 at its own size: the oracle's TripletNet_Finetune forward on 256 images of 256x256 (eval mode; one backbone
+    pass per image) against reductions of the reference module's own output (tests/golden/make_golden.py:gen_fwd_full)."""
+    g = load_golden("fwd_full")
+    pn, bn, _ = oracle_state("finetune", 1, True)
+    x = C.u8(5100, (256, 3, 256, 256)).float()
+    with torch.no_grad():
+        feats = OM.finetune_forward(pn, bn, x, False, faithful=False).double()
+    assert rel_err(feats.norm(dim=1), g["fwd_full/eval/feats_rowl2"]) < 2e-4
+    assert rel_err(feats.sum(0), g["fwd_full/eval/feats_colsum"]) < 2e-4
+    assert rel_err(feats[:4].float(), g["fwd_full/eval/feats_head"]) < 2e-4
+
+
 def test_kather_supervised():
     """config 1's script, eval_Kather_SSL.train/validate (the slice of the reference file above ``def parse_args``), 96x96."""
     name = "kather_sup"
