@@ -320,6 +320,12 @@ class Engine:
             L.check(L.lib().sslcr_comm_all_reduce_f32(self.handle, L.ptr(t), t.numel(), L.stream_ptr()))
         return t
 
+    def copy_stream(self):
+        """side stream for host-to-device prefetch of the next batch (steps._ahead); torch owns streams, the engine only keeps one"""
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(self.device)
+        return self._copy_stream
+
     # ------------------------------------------------------------------ measurement
     def profile(self, enable):
         L.check(L.lib().sslcr_profile(self.handle, int(enable)))

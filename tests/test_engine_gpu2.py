@@ -611,3 +611,37 @@ def test_cam_wsi_slide_sized_map_vs_reference(dtype):
     err = float(np.abs(pm - want).max())
     print(f"[{dtype}] slide-sized probability map: max abs error {err:.2e} (values 0.23..0.33)")
     assert err <= {"fp32": 1e-4, "bf16": 2e-2, "fp8": 3e-2}[dtype], err
+
+
+@pytest.mark.parametrize("script", ["bpq_cr", "rsp"])
+def test_device_prefetch_of_host_batches_is_the_same_epoch(script):
+    """steps._ahead: with ``args.device_prefetch`` the next batch's images go host -> device on a copy stream while the current
+    step runs (event-ordered, record_stream'ed).  Three iterations from pinned host loaders must give the same results with and
+    without it (same kernels, same inputs; only when the copy happens differs): equal losses and features, post-step state equal to
+    the order of the weight gradients' fp32 atomics -- for a two-loader SSL_CR epoch and the four-tensor RSP epoch."""
+    from ssl_cr_histo_amd import steps
+    _engine("bf16")
+    hw, b, mu = 64, 2, 3
+    outs = []
+    for pre in (False, True):
+        a = ns(lambda_u=0.7, tile_h=hw, tile_w=hw, device_prefetch=pre)
+        if script == "bpq_cr":
+            lab = [(C.u8(9400 + i, (b, 3, 3, 256, 256)).pin_memory(), C.f32(9410 + i, (b, 3))) for i in range(3)]
+            unl = [(C.u8(9420 + i, (b * mu, 3, 256, 256)).pin_memory(), C.u8(9430 + i, (b * mu, 3, 256, 256)).pin_memory()) for i in range(3)]
+            mt, ct = build("finetune", "finetune", 1, True)
+            ms, cs = build("finetune", "finetune", 1, True)
+            freeze(mt, 64)
+            opt = torch.optim.Adam(list(ms.parameters()) + list(cs.parameters()), lr=1e-4, weight_decay=1e-4)
+            r = steps.bpq_cr_train(a, mt, ms, ct, cs, lab, unl, opt, 1)
+            outs.append((r[0], r[1], r[2], r[3].cpu(), state_of(ms, cs)))
+        else:
+            batches = [tuple(C.u8(9440 + 4 * i + j, (b, 3, hw, hw)).pin_memory() for j in range(3)) + (C.ints(9460 + i, (b,), 6),) for i in range(3)]
+            model, cls = build("triplet", "mlp", 6, False)
+            opt = torch.optim.SGD(list(model.parameters()) + list(cls.parameters()), lr=0.01, momentum=0.9, weight_decay=1e-4, nesterov=True)
+            r = steps.rsp_train(a, model, cls, batches, torch.nn.CrossEntropyLoss(), opt, 1)
+            outs.append((r[0], r[1], 0.0, r[2].cpu(), state_of(model, cls)))
+    x, y = outs
+    assert x[0] == y[0] and x[1] == y[1] and x[2] == y[2]
+    assert torch.equal(x[3], y[3])
+    for k in x[4]:          # (weight gradients sum fp32 atomics in launch-dependent order: the state agrees to that, not to the bit)
+        assert torch.allclose(x[4][k].float(), y[4][k].float(), rtol=1e-4, atol=1e-6), k
