@@ -645,3 +645,34 @@ def test_device_prefetch_of_host_batches_is_the_same_epoch(script):
     assert torch.equal(x[3], y[3])
     for k in x[4]:          # (weight gradients sum fp32 atomics in launch-dependent order: the state agrees to that, not to the bit)
         assert torch.allclose(x[4][k].float(), y[4][k].float(), rtol=1e-4, atol=1e-6), k
+
+
+def test_bench_line_contract():
+    """bench.py's ONE JSON line on a short run of the headline workload: the driver's fields, the roofline object with counters
+    measured in this run (rocprofv3 is part of the image), and agreement between the HIP-event duration of the dominant kernel and
+    the algorithmic work it books."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--no-also", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1088 / (d["ms_per_step"] * 1e-3)) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["peak"] == 2500.0 and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["algorithmic_gflop_per_launch"] / r["avg_launch_us"] * 1e3) <= 0.01 * r["achieved"]   # GFLOP / us = PFLOP/s
+    assert 0.2 < r["frac"] < 1.0
+    assert d["pmc_status"]["measured_in_run"] is True, d["pmc_status"]
+    assert r["pmc"]["measured_in_run"] is True and 0.2 < r["pmc"]["mfma_busy"] < 1.0 and r["traffic"] > 1e8
+    assert 20.0 < d["mfma_util_pct"] < 100.0 and 30.0 < d["hbm_traffic_gb_per_step"] < 120.0
