@@ -127,6 +127,12 @@ typedef struct sslcr_stem_desc {
 } sslcr_stem_desc;
 int sslcr_stem_conv(int dtype, const sslcr_stem_desc* d, void* stream);
 int sslcr_stem_partial_rows(const sslcr_stem_desc* d);
+/* eval-mode stem in one launch: conv1 (BatchNorm folded into d->w / d->bias) -> ReLU -> maxpool 3x3/2 pad 1, i.e. resnet18.conv1 ..
+ * .maxpool as the teacher forward, validate() and test_Camelyon16.py reach them (models/net.py:32,77 under model.eval()).  d->y is the
+ * POOLED output [N][POH][POW][64] (POH = OH / 2, POW = OW / 2); the conv output never reaches HBM.  bf16, d->relu set, d->stats NULL,
+ * OH and OW multiples of 16 with 32 <= OW <= 256; other shapes fail (sslcr_stem_conv + sslcr_bn_relu_maxpool serve them, with the same
+ * bits where both apply). */
+int sslcr_stem_conv_pool(int dtype, const sslcr_stem_desc* d, int POH, int POW, void* stream);
 typedef struct sslcr_stem_wgrad_desc {
   const void* x; const void* dy;
   float* dw;              /* [64][3][7][7] fp32 (PyTorch layout), accumulated */

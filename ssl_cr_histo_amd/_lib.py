@@ -85,6 +85,7 @@ SIGNATURES = {
     "sslcr_probe_tr16": (i32, [vp, vp, vp, vp]),
     "sslcr_stem_conv": (i32, [i32, P(StemDesc), vp]),
     "sslcr_stem_partial_rows": (i32, [P(StemDesc)]),
+    "sslcr_stem_conv_pool": (i32, [i32, P(StemDesc), i32, i32, vp]),
     "sslcr_stem_wgrad": (i32, [i32, P(StemWgradDesc), vp]),
     "sslcr_stem_wgrad_pool": (i32, [i32, P(StemWgradDesc), P(BnBwdDesc), vp]),
     "sslcr_bn_finalize": (i32, [P(BnFinalizeDesc), vp]),

@@ -78,6 +78,12 @@ int sslcr_stem_conv(int dtype, const sslcr_stem_desc* d, void* stream) {
   NEED(!d->x2 || (d->n_split >= 0 && d->n_split <= d->N), "n_split outside the batch");
   return check(launch_stem(dtype, *d, (hipStream_t)stream), "stem_conv");
 }
+int sslcr_stem_conv_pool(int dtype, const sslcr_stem_desc* d, int POH, int POW, void* stream) {
+  DT_OK(dtype);
+  NEED(d && d->x && d->w && d->y, "null");
+  NEED(stem_pool_ok(dtype, *d, POH, POW), "shape / mode not served by the fused stem + max-pool kernel");
+  return check(launch_stem_pool(dtype, *d, POH, POW, (hipStream_t)stream), "stem_conv_pool");
+}
 int sslcr_stem_partial_rows(const sslcr_stem_desc* d) { return d ? stem_partials_rows(*d) : -1; }
 int sslcr_stem_wgrad(int dtype, const sslcr_stem_wgrad_desc* d, void* stream) {
   DT_OK(dtype);

@@ -694,12 +694,17 @@ int backbone_forward_eval(sslcr_net* n, const void* x, int in_f32, int N, int H,
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = n->stem.w_fold; a.y = base + o_a0; a.bias = n->stem.b_fold; a.relu = 1;
     a.N = N; a.H = H; a.W = W; a.OH = d.oh0; a.OW = d.ow0; a.in_f32 = in_f32;
-    TRY(launch_stem(dt, a, st));
-    PoolFwdArgs p;
-    memset(&p, 0, sizeof(p));
-    p.x = base + o_a0; p.y = base + o_buf[0];            // plain max-pool: the stem's epilogue applied the folded BatchNorm + ReLU
-    p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
-    TRY(launch_bn_relu_maxpool(dt, p, st));
+    if (stem_pool_ok(dt, a, d.ph, d.pw)) {
+      a.y = base + o_buf[0];                               // conv1 + folded BatchNorm + ReLU + max-pool in one launch: the conv output stays on the CU
+      TRY(launch_stem_pool(dt, a, d.ph, d.pw, st));
+    } else {
+      TRY(launch_stem(dt, a, st));
+      PoolFwdArgs p;
+      memset(&p, 0, sizeof(p));
+      p.x = base + o_a0; p.y = base + o_buf[0];            // plain max-pool: the stem's epilogue applied the folded BatchNorm + ReLU
+      p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
+      TRY(launch_bn_relu_maxpool(dt, p, st));
+    }
   }
   int xi = 0, xh = d.ph, xw = d.pw;
   for (int i = 0; i < 8; ++i) {

@@ -70,6 +70,9 @@ hipError_t launch_stem(int dtype, const StemArgs& a, hipStream_t st);
 int stem_partials_rows(const StemArgs& a);
 hipError_t launch_stem_wgrad(int dtype, const StemWgradArgs& a, hipStream_t st);
 hipError_t launch_stem_wgrad_pool(int dtype, const StemWgradArgs& a, const sslcr_bn_bwd_desc& b, hipStream_t st);
+// stem_pool.hip: eval-mode stem + max-pool in one kernel (bf16)
+bool stem_pool_ok(int dtype, const StemArgs& a, int POH, int POW);
+hipError_t launch_stem_pool(int dtype, const StemArgs& a, int POH, int POW, hipStream_t st);
 // bn_eltwise.hip
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st);
 hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st);

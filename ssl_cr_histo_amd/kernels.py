@@ -168,6 +168,22 @@ def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False, x2=N
     return (y, stats) if want_stats else y
 
 
+def stem_conv_pool(x_nchw, w_packed, bias, *, x2=None):
+    """eval-mode stem in one launch: conv1 (folded BatchNorm: bias) -> ReLU -> maxpool 3x3/2 pad 1 -> NHWC [N, OH/2, OW/2, 64] (bf16)."""
+    _chk(x_nchw, w_packed, bias, x2)
+    N, _, H, W = x_nchw.shape
+    n_split = 0
+    if x2 is not None:
+        n_split, N = N, N + x2.shape[0]
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    POH, POW = OH // 2, OW // 2
+    y = torch.empty((N, POH, POW, 64), dtype=w_packed.dtype, device=x_nchw.device)
+    d = L.StemDesc(L.ptr(x_nchw), L.ptr(w_packed), L.ptr(y), L.ptr(bias), None, N, H, W, OH, OW,
+                   int(x_nchw.dtype == torch.float32), 1, L.ptr(x2), int(n_split))
+    L.check(L.lib().sslcr_stem_conv_pool(_dt(w_packed), d, POH, POW, L.stream_ptr()))
+    return y
+
+
 def stem_wgrad(x_nchw, dy, dw, *, x2=None):
     _chk(x_nchw, dy, dw, x2)
     N, _, H, W = x_nchw.shape

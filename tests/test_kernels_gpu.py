@@ -806,3 +806,45 @@ def test_conv_pingpong_64(case, op):
     else:
         y = out
     close(y, want, TOL[dtype], f"pp64 {op}")
+
+
+@pytest.mark.parametrize("in_u8", [True, False])
+@pytest.mark.parametrize("shape,split", [((2, 64, 64), 0), ((3, 256, 256), 0), ((5, 224, 224), 2), ((260, 64, 96), 0), ((3, 96, 64), 1)])
+def test_stem_conv_pool_fused(shape, split, in_u8):
+    """sslcr_stem_conv_pool (eval-mode conv1 + folded BatchNorm + ReLU + maxpool 3x3/2 in one launch, the conv output never in HBM)
+    against (a) the oracle ops and (b) the two-kernel path it replaces, bit for bit: several bands and tile columns, more images than
+    workgroups (260 > 256: a workgroup walks into its second image), non-square maps, a two-segment input, uint8 and fp32 input."""
+    K = _k()
+    N, H, W = shape
+    dtype = 1
+    xu = torch.from_numpy(np.random.RandomState(131).randint(0, 256, (N, 3, H, W), dtype=np.uint8))
+    w = rnd(132, (64, 3, 7, 7), 0.03)
+    g, b, rm, rv = rnd(133, (64,)).abs() + 0.5, rnd(134, (64,)), rnd(135, (64,)), rnd(136, (64,)).abs() + 0.5
+    wp, bias = K.pack_stem(w.to(DEV), dtype, bn=tuple(t.to(DEV) for t in (g, b, rm, rv)))
+    xin = (xu if in_u8 else xu.float()).to(DEV)
+    if split:
+        got = K.stem_conv_pool(xin[:split].contiguous(), wp, bias, x2=xin[split:].contiguous())
+    else:
+        got = K.stem_conv_pool(xin, wp, bias)
+    conv = K.stem_conv(xin, wp, bias=bias, relu=True)
+    two, _ = K.bn_relu_maxpool(conv, None, None)
+    assert got.shape == two.shape
+    assert torch.equal(got.view(torch.int16), two.view(torch.int16)), float((got.float() - two.float()).abs().max())
+    if N <= 5:
+        f = g / torch.sqrt(rv + 1e-5)
+        ref = F.relu(F.conv2d(xu.float(), q(w * f.view(-1, 1, 1, 1), dtype), None, 2, 3) + (b - rm * f).view(1, -1, 1, 1))
+        want = R.nhwc(F.max_pool2d(ref, 3, 2, 1))
+        close(got, want, TOL[dtype], "fused stem + pool")
+
+
+def test_stem_conv_pool_rejects_unserved_shapes():
+    K = _k()
+    from ssl_cr_histo_amd import _lib as L
+    w = rnd(132, (64, 3, 7, 7), 0.03)
+    wp, bias = K.pack_stem(w.to(DEV), 1, bn=tuple(torch.ones(64, device=DEV) for _ in range(4)))
+    for shape in [(2, 3, 56, 40), (1, 3, 32, 32), (2, 3, 30, 34)]:       # conv output not 16-tileable / a single tile column
+        with pytest.raises(L.SslcrError):
+            K.stem_conv_pool(torch.zeros(shape, dtype=torch.uint8, device=DEV), wp, bias)
+    wp32, bias32 = K.pack_stem(w.to(DEV), 0, bn=tuple(torch.ones(64, device=DEV) for _ in range(4)))
+    with pytest.raises(L.SslcrError):
+        K.stem_conv_pool(torch.zeros((2, 3, 64, 64), dtype=torch.uint8, device=DEV), wp32, bias32)
