@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
       it_slab = 0;
       do { ++it_tap; } while (it_tap < RS && !((tmask >> it_tap) & 1u));
     }
-    const int r = tap / a.S, s = tap - r * a.S;
+    int r = 0, s = tap;                          // (uniform; a subtract loop instead of a division per step)
+    while (s >= a.S) { s -= a.S; ++r; }
     char* sb = smem + stage * STG;
 #pragma unroll
     for (int i = 0; i < PLD; ++i) {

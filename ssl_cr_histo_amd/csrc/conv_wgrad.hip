@@ -28,23 +28,27 @@ template <> struct WgFrag<bf16_t> {
   }
 };
 
-template <typename T, int TAPS>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int steps_per_split, f32x4_t* partials) {
+// KH = 64-kout halves per workgroup (256 threads each).  KH = 2 reads X once per 128 kouts instead of once per 64: these
+// launches are HBM-bound on that re-read (r03: 874 MB per launch against 503 MB of tensors at KH = 1).
+template <typename T, int TAPS, int KH>
+__global__ __launch_bounds__(256 * KH, 2) void wgrad_kernel(const WgradArgs a, int steps_per_split, f32x4_t* partials) {
   constexpr int EPC = Elem<T>::EPC;
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int PS = BF ? 32 : 16;             // pixels per step
   constexpr int RB = 64 * sizeof(T);           // bytes per LDS row (64 channels)
   constexpr int CPR = RB / 16;                 // 16-byte chunks per row
   constexpr int TILE = PS * RB;                // 4 KiB
-  constexpr int BUF = (1 + TAPS) * TILE;
+  constexpr int BUF = (KH + TAPS) * TILE;      // KH dY tiles, then one X tile per tap
+  constexpr int NT = 256 * KH;
+  constexpr int NX = (TAPS + KH - 1) / KH;     // X taps staged per thread: tap KH*i + kh
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kh = tid >> 8;
   const int li = lane & 15, g = lane >> 4;
-  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int k0 = blockIdx.x * (64 * KH), c0 = blockIdx.y * 64;
   const int OHW = a.OH * a.OW;
   const int M = a.N * OHW;
-  const int row = tid / CPR, chunk = tid % CPR;
+  const int row = (tid & 255) / CPR, chunk = (tid & 255) % CPR;
   const bool xform = a.in_scale != nullptr;
   // this thread always stages the same EPC channels: keep their BN scale/shift in registers (LDS is exactly 2 x 40 KiB,
   // so two workgroups share a CU's 160 KiB)
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int st
   if (nsteps <= 0) {                            // (the launcher sizes the splits so that none is empty; a slab must still be defined)
     if (partials) {
       const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-      for (int e = 0; e < TAPS * 4; ++e) partials[(wg * (TAPS * 4) + e) * 256 + tid] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      for (int e = 0; e < TAPS * 4; ++e) partials[(wg * (TAPS * 4) + e) * NT + tid] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     return;
   }
@@ -70,36 +74,51 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int st
   const char* xg = reinterpret_cast<const char*>(a.x);
   const char* dyg = reinterpret_cast<const char*>(a.dy);
 
-  u32x4_t yreg, xreg[TAPS];
+  // pixel -> (image, row, column) once per step and thread: a reciprocal estimate plus one correction instead of
+  // integer divisions
+  constexpr int TS = TAPS == 9 ? 3 : 1;        // filter width, known from the tap count
+  const float rcp_ohw = 1.f / (float)OHW, rcp_ow = 1.f / (float)a.OW;
+  auto divmod = [](int x, int d, float rcp, int& q, int& r) {
+    q = (int)((float)x * rcp);
+    r = x - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+  };
+
+  u32x4_t yreg, xreg[NX];
   unsigned inb = 0;
   auto load_regs = [&](int s) {
     const int m = (step0 + s) * PS + row;
     inb = 0;
     yreg = u32x4_t{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) xreg[t] = u32x4_t{0u, 0u, 0u, 0u};
+    for (int i = 0; i < NX; ++i) xreg[i] = u32x4_t{0u, 0u, 0u, 0u};
     if (m < M) {
-      yreg = ld16(dyg + ((size_t)m * a.K + k0 + chunk * EPC) * sizeof(T));
-      const int n = m / OHW, rem = m - n * OHW;
-      const int ho = rem / a.OW, wo = rem - ho * a.OW;
+      yreg = ld16(dyg + ((size_t)m * a.K + k0 + 64 * kh + chunk * EPC) * sizeof(T));
+      int n, rem, ho, wo;
+      divmod(m, OHW, rcp_ohw, n, rem);
+      divmod(rem, a.OW, rcp_ow, ho, wo);
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int r = t / a.S, s_ = t - r * a.S;
+      for (int i = 0; i < NX; ++i) {
+        const int t = KH * i + kh;
+        const int r = KH == 1 ? t / TS : (t >= TS) + (t >= 2 * TS), s_ = t - r * TS;
         const int h = ho * a.stride - a.pad + r, w = wo * a.stride - a.pad + s_;
-        if (h >= 0 && w >= 0 && h < a.H && w < a.W) {
-          xreg[t] = ld16(xg + ((size_t)((n * a.H + h) * a.W + w) * a.C + c0 + chunk * EPC) * sizeof(T));
-          inb |= 1u << t;
+        if (t < TAPS && h >= 0 && w >= 0 && h < a.H && w < a.W) {
+          xreg[i] = ld16(xg + ((size_t)((n * a.H + h) * a.W + w) * a.C + c0 + chunk * EPC) * sizeof(T));
+          inb |= 1u << i;
         }
       }
     }
   };
   auto store_lds = [&](int buf) {
     char* b = smem + buf * BUF;
-    st16(b + row * RB + chunk * 16, yreg);
+    st16(b + kh * TILE + row * RB + chunk * 16, yreg);
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      u32x4_t v = xreg[t];
-      if (xform && ((inb >> t) & 1u)) {
+    for (int i = 0; i < NX; ++i) {
+      const int t = KH * i + kh;
+      if (TAPS % KH != 0 && t >= TAPS) continue;
+      u32x4_t v = xreg[i];
+      if (xform && ((inb >> i) & 1u)) {
         float f[EPC];
         Elem<T>::unpack(v, f);
 #pragma unroll
@@ -109,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int st
         }
         v = Elem<T>::pack(f);
       }
-      st16(b + (1 + t) * TILE + row * RB + chunk * 16, v);
+      st16(b + (KH + t) * TILE + row * RB + chunk * 16, v);
     }
   };
 
@@ -126,14 +145,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int st
     const bool more = s + 1 < nsteps;
     if (more) load_regs(s + 1);
     const char* b = smem + (s & 1) * BUF;
-    // wave w owns cin tile w and all four kout tiles: 4 A + TAPS B fragments feed 4*TAPS MFMAs per step
+    // wave (kh, w) owns cin tile w and the four kout tiles of half kh: 4 A + TAPS B fragments feed 4*TAPS MFMAs per step
     if constexpr (BF) {
       bf16x8_t af[4];
 #pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) af[t4] = WgFrag<bf16_t>::load(b, 16 * t4, li, g);
+      for (int t4 = 0; t4 < 4; ++t4) af[t4] = WgFrag<bf16_t>::load(b + kh * TILE, 16 * t4, li, g);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
-        const bf16x8_t bfrag = WgFrag<bf16_t>::load(b + (1 + t) * TILE, 16 * wave, li, g);
+        const bf16x8_t bfrag = WgFrag<bf16_t>::load(b + (KH + t) * TILE, 16 * wave, li, g);
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[t4], bfrag, acc[t][t4], 0, 0, 0);
       }
@@ -143,10 +162,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int st
         const int prow = 4 * q + g;
         float av[4];
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) av[t4] = *reinterpret_cast<const float*>(b + prow * RB + (16 * t4 + li) * 4);
+        for (int t4 = 0; t4 < 4; ++t4) av[t4] = *reinterpret_cast<const float*>(b + kh * TILE + prow * RB + (16 * t4 + li) * 4);
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
-          const float bv = *reinterpret_cast<const float*>(b + (1 + t) * TILE + prow * RB + (16 * wave + li) * 4);
+          const float bv = *reinterpret_cast<const float*>(b + (KH + t) * TILE + prow * RB + (16 * wave + li) * 4);
 #pragma unroll
           for (int t4 = 0; t4 < 4; ++t4) acc[t][t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t4], bv, acc[t][t4], 0, 0, 0);
         }
@@ -156,15 +175,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int st
     __syncthreads();
   }
 
-  // acc[tap][t4]: D[row = kout 16*t4+4g+j][col = cin 16*wave+li]  ->  dW[k][tap][c]
+  // acc[tap][t4]: D[row = kout 64*kh+16*t4+4g+j][col = cin 16*wave+li]  ->  dW[k][tap][c]
   const int RS = a.R * a.S;
   if (partials) {                               // accumulator slab + fold launch instead of atomics from here, see wgrad_halo.hip
     const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    f32x4_t* sp = partials + wg * (TAPS * 4) * 256 + tid;
+    f32x4_t* sp = partials + wg * (TAPS * 4) * NT + tid;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-      for (int t4 = 0; t4 < 4; ++t4) sp[(size_t)(t * 4 + t4) * 256] = acc[t][t4];
+      for (int t4 = 0; t4 < 4; ++t4) sp[(size_t)(t * 4 + t4) * NT] = acc[t][t4];
     return;
   }
 #pragma unroll
@@ -173,42 +192,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a, int st
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int k = k0 + 16 * t4 + 4 * g + j;
+        const int k = k0 + 64 * kh + 16 * t4 + 4 * g + j;
         atomicAdd(a.dw + ((size_t)k * RS + t) * a.C + c0 + 16 * wave + li, acc[t][t4][j]);
       }
 }
 
-template <typename T, int TAPS>
+static bool wgrad_wide(int dtype, const WgradArgs& a) {
+  static const bool on = [] { const char* e = getenv("SSLCR_WGRAD_WIDE"); return !(e && e[0] == '0'); }();
+  return on && dtype == DT_BF16 && a.K % 128 == 0;
+}
+
+template <typename T, int TAPS, int KH>
 static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
   constexpr int PS = Elem<T>::DT == DT_BF16 ? 32 : 16;
   const int M = a.N * a.OH * a.OW;
   const int total_steps = cdiv(M, PS);
-  const int tiles = (a.K / 64) * (a.C / 64);
-  // one resident round (two workgroups per CU): the pixel split sets how many fp32 atomics hit dW, see wgrad_halo.hip
+  const int tiles = (a.K / (64 * KH)) * (a.C / 64);
+  // one resident round (160 KiB of LDS per CU = two narrow or one wide workgroup): the pixel split sets how many fp32
+  // atomics hit dW, see wgrad_halo.hip
   int cus = 256;
   {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  int splits = cdiv(TAPS == 1 ? 4 * cus : 2 * cus, tiles);     // 1x1: few atomics per workgroup, more parallel slices pay
+  int splits = cdiv((TAPS == 1 ? 4 * cus : 2 * cus) / KH, tiles);     // 1x1: few atomics per workgroup, more parallel slices pay
   const int max_splits = cdiv(total_steps, 8);      // at least 8 steps per workgroup
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const int sps = cdiv(total_steps, splits);
   splits = cdiv(total_steps, sps);
-  const size_t lds = 2 * (1 + TAPS) * 4096;
-  auto kern = wgrad_kernel<T, TAPS>;
+  const size_t lds = 2 * (KH + TAPS) * 4096;
+  auto kern = wgrad_kernel<T, TAPS, KH>;
   static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int gx = a.K / 64, gy = a.C / 64;
+  const int gx = a.K / (64 * KH), gy = a.C / 64;
   f32x4_t* slabs = (Elem<T>::DT == DT_BF16 && splits > 1 && TAPS == a.R * a.S)
-                       ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * TAPS * 4 * 256 * sizeof(f32x4_t))) : nullptr;
-  hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(256), lds, st, a, sps, slabs);
-  if (slabs) return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, TAPS, 1, st);
+                       ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * TAPS * 4 * 256 * KH * sizeof(f32x4_t))) : nullptr;
+  hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(256 * KH), lds, st, a, sps, slabs);
+  if (slabs) return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, TAPS, KH, st);
   return hipGetLastError();
 }
 
@@ -232,8 +257,9 @@ const char* wgrad_kernel_name(int dtype, const WgradArgs& a) {
   const bool wide = bf && a.K % 128 == 0;          // the 128-kout block, 8-wave form (wgrad_halo.hip)
   if (tw == 16) return bf ? (wide ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 16, 2>" : "sslcr::wgrad3x3_halo_kernel<unsigned short, 16, 1>") : "sslcr::wgrad3x3_halo_kernel<float, 16, 1>";
   if (tw == 8) return bf ? (wide ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 8, 2>" : "sslcr::wgrad3x3_halo_kernel<unsigned short, 8, 1>") : "sslcr::wgrad3x3_halo_kernel<float, 8, 1>";
-  if (a.R == 3) return bf ? "sslcr::wgrad_kernel<unsigned short, 9>" : "sslcr::wgrad_kernel<float, 9>";
-  return bf ? "sslcr::wgrad_kernel<unsigned short, 1>" : "sslcr::wgrad_kernel<float, 1>";
+  const bool kw = wgrad_wide(dtype, a);
+  if (a.R == 3) return bf ? (kw ? "sslcr::wgrad_kernel<unsigned short, 9, 2>" : "sslcr::wgrad_kernel<unsigned short, 9, 1>") : "sslcr::wgrad_kernel<float, 9, 1>";
+  return bf ? (kw ? "sslcr::wgrad_kernel<unsigned short, 1, 2>" : "sslcr::wgrad_kernel<unsigned short, 1, 1>") : "sslcr::wgrad_kernel<float, 1, 1>";
 }
 
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st) {
@@ -241,8 +267,9 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st) {
   if (tw) return launch_wgrad_halo(dtype, a, tw, st);
   if (a.seg_images > 0 && a.seg_images < a.N) return hipErrorInvalidValue;      // per-segment prologue: halo kernel only
   const bool three = a.R == 3;
-  if (dtype == DT_BF16) return three ? launch_w<bf16_t, 9>(a, st) : launch_w<bf16_t, 1>(a, st);
-  return three ? launch_w<float, 9>(a, st) : launch_w<float, 1>(a, st);
+  if (wgrad_wide(dtype, a)) return three ? launch_w<bf16_t, 9, 2>(a, st) : launch_w<bf16_t, 1, 2>(a, st);
+  if (dtype == DT_BF16) return three ? launch_w<bf16_t, 9, 1>(a, st) : launch_w<bf16_t, 1, 1>(a, st);
+  return three ? launch_w<float, 9, 1>(a, st) : launch_w<float, 1, 1>(a, st);
 }
 
 }  // namespace sslcr
