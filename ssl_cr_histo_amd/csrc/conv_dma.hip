@@ -70,23 +70,39 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   const unsigned tmask = a.par4 ? tm4 : (a.tap_mask ? a.tap_mask : ((1u << RS) - 1u));
   const int nsteps = __builtin_popcount(tmask) * cslabs;
 
-  // ---- DMA roles: instruction i of this wave fills LDS rows [i*32 + wave*8, +8); lane -> (row, 16-byte slot)
+  // ---- DMA roles: instruction i of this wave fills LDS rows [i*32 + wave*8, +8); lane -> (row, 16-byte slot).
+  // A lane keeps the base coordinates (h0, w0) of its pixel and the ADDRESS of that (possibly out-of-image) position; a tap
+  // then adds a displacement (dh, dw) that is uniform over the workgroup -- one 64-bit add and two range checks per DMA
+  // instead of the per-lane multiply chain (r03: this kernel ran ~6 VALU instructions per MFMA, most of them addresses and
+  // integer divisions).  Transposed stride 2 needs a uniform pixel parity for that: pix_mul even (conv_dma_bp).
+  const float rcp_phw = 1.f / (float)PHW, rcp_pw = 1.f / (float)a.PW;
+  auto divmod = [](int x, int d, float rcp, int& q, int& r) {      // reciprocal estimate + one correction
+    q = (int)((float)x * rcp);
+    r = x - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+  };
+  const int tsh = (a.transposed && a.stride == 2) ? 1 : 0;
+  const int e_h = (off_h + a.pad) & 1, e_w = (off_w + a.pad) & 1;      // transposed stride 2: parity of (p + pad)
+  const char* xg = reinterpret_cast<const char*>(a.x);
   const int slot = lane & 7;
-  int pbase[PLD], hb[PLD], wb[PLD], pc16[PLD];
+  int h0[PLD], w0[PLD];
+  const char* rowp[PLD];
 #pragma unroll
   for (int i = 0; i < PLD; ++i) {
     const int rr = i * 32 + wave * 8 + (lane >> 3);
     const int m = m0 + rr;
-    pc16[i] = ((slot ^ (rr & 7)) * EPC) * (int)sizeof(T);
+    const int pc16 = ((slot ^ (rr & 7)) * EPC) * (int)sizeof(T);
     if (m < M) {
-      const int n = m / PHW, rem = m - n * PHW;
-      int ph = rem / a.PW, pw = rem - ph * a.PW;
+      int n, rem, ph, pw;
+      divmod(m, PHW, rcp_phw, n, rem);
+      divmod(rem, a.PW, rcp_pw, ph, pw);
       ph = ph * pmul + off_h; pw = pw * pmul + off_w;
-      pbase[i] = n * a.H * a.W;
-      hb[i] = a.transposed ? ph + a.pad : ph * a.stride - a.pad;
-      wb[i] = a.transposed ? pw + a.pad : pw * a.stride - a.pad;
+      h0[i] = a.transposed ? (ph + a.pad) >> tsh : ph * a.stride - a.pad;
+      w0[i] = a.transposed ? (pw + a.pad) >> tsh : pw * a.stride - a.pad;
+      rowp[i] = xg + ((long)n * a.H * a.W + (long)h0[i] * a.W + w0[i]) * (long)(a.C * (int)sizeof(T)) + pc16;
     } else {
-      pbase[i] = -1; hb[i] = 0; wb[i] = 0;
+      h0[i] = -(1 << 24); w0[i] = 0; rowp[i] = xg;           // never in range
     }
   }
   int wsrc[WLD];
@@ -98,11 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     const int krow = blk * 64 + ((x >> 2) & 3) * 16 + (x >> 4) * 4 + (x & 3);
     wsrc[i] = (int)((((size_t)(k0 + krow) * RS) * a.C + (slot ^ (rr & 7)) * EPC) * sizeof(T));
   }
-  const char* xg = reinterpret_cast<const char*>(a.x);
   const char* wg = reinterpret_cast<const char*>(a.w);
   const char* zpage = reinterpret_cast<const char*>(g_conv_zero_page) + slot * 16;
 
-  const int ssh = a.stride == 2 ? 1 : 0, smask = a.stride - 1;     // transposed form: stride 1 or 2 only (conv_dma_bp)
   int it_tap = __builtin_ctz(tmask), it_slab = 0;      // issue() is called for steps 0,1,2,... in order
   auto issue = [&](int stage) {
     const int tap = it_tap, c0 = it_slab * CE;
@@ -112,21 +126,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     }
     int r = 0, s = tap;                          // (uniform; a subtract loop instead of a division per step)
     while (s >= a.S) { s -= a.S; ++r; }
+    // the tap's displacement from (h0, w0): r, s forward; -r, -s transposed; (parity - r) / 2 where that divides, stride 2
+    const int th = e_h - r, tw = e_w - s;
+    const int dh = a.transposed ? (tsh ? th >> 1 : -r) : r, dw = a.transposed ? (tsh ? tw >> 1 : -s) : s;
+    const bool tap_ok = !tsh || ((th | tw) & 1) == 0;
+    const long uoff = ((long)(dh * a.W + dw) * a.C + c0) * (long)sizeof(T);
     char* sb = smem + stage * STG;
 #pragma unroll
     for (int i = 0; i < PLD; ++i) {
-      int h, w;
-      bool ok = pbase[i] >= 0;
-      if (a.transposed) {                        // dgrad gather: source pixel (p + pad - r) / stride where that divides
-        const int th = hb[i] - r, tw = wb[i] - s;
-        h = th >> ssh; w = tw >> ssh;
-        ok = ok && th >= 0 && tw >= 0 && ((th | tw) & smask) == 0;
-      } else {
-        h = hb[i] + r; w = wb[i] + s;
-        ok = ok && h >= 0 && w >= 0;
-      }
-      ok = ok && h < a.H && w < a.W;
-      const char* src = ok ? xg + ((size_t)(pbase[i] + h * a.W + w) * a.C + c0) * sizeof(T) + pc16[i] : zpage;
+      const bool ok = tap_ok && (unsigned)(h0[i] + dh) < (unsigned)a.H && (unsigned)(w0[i] + dw) < (unsigned)a.W;
+      const char* src = ok ? rowp[i] + uoff : zpage;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (i * 32 + wave * 8) * 128), 16, 0, 0);
     }
     const char* wtap = wg + ((size_t)tap * a.C + c0) * sizeof(T);
@@ -202,8 +211,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     const int mm = m0 + wp * 64 + p * 16 + li;
     ok[p] = mm < M;
     const int m = ok[p] ? mm : M - 1;          // a valid pixel for the (unconditional) operand loads
-    const int n = m / PHW, rem = m - n * PHW;
-    int ph = rem / a.PW, pw = rem - ph * a.PW;
+    int n, rem, ph, pw;
+    divmod(m, PHW, rcp_phw, n, rem);
+    divmod(rem, a.PW, rcp_pw, ph, pw);
     ph = ph * pmul + off_h; pw = pw * pmul + off_w;
     const size_t opix = ((size_t)n * a.OH + (size_t)ph * a.osh) * a.OW + (size_t)pw * a.osh;
     off[p] = (opix * a.K + kb) * sizeof(T);
@@ -241,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
 int conv_dma_bp(int dtype, const ConvArgs& a) {
   if (a.in_scale != nullptr) return 0;
   if (a.transposed && a.stride != 1 && a.stride != 2) return 0;
+  if (a.transposed && a.stride == 2 && ((a.pix_mul ? a.pix_mul : 1) & 1)) return 0;      // the kernel wants one pixel parity per workgroup (pix_mul 0 = 1)
   const int ce = dtype == DT_BF16 ? 64 : 32;
   if (a.C % ce != 0 || a.K % 64 != 0 || a.R * a.S > 31) return 0;
   const long M = (long)a.N * a.PH * a.PW;
