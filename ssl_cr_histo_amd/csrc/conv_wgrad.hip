@@ -98,14 +98,28 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad_kernel(const WgradArgs a, i
       int n, rem, ho, wo;
       divmod(m, OHW, rcp_ohw, n, rem);
       divmod(rem, a.OW, rcp_ow, ho, wo);
+      if constexpr (KH == 2) {
+        // address of the (possibly out-of-image) tap (0, 0) position once; a tap adds a uniform offset
+        const int h0 = ho * a.stride - a.pad, w0 = wo * a.stride - a.pad;
+        const char* xp = xg + (((long)n * a.H + h0) * a.W + w0) * (long)(a.C * (int)sizeof(T)) + (c0 + chunk * EPC) * (int)sizeof(T);
 #pragma unroll
-      for (int i = 0; i < NX; ++i) {
-        const int t = KH * i + kh;
-        const int r = KH == 1 ? t / TS : (t >= TS) + (t >= 2 * TS), s_ = t - r * TS;
-        const int h = ho * a.stride - a.pad + r, w = wo * a.stride - a.pad + s_;
-        if (t < TAPS && h >= 0 && w >= 0 && h < a.H && w < a.W) {
-          xreg[i] = ld16(xg + ((size_t)((n * a.H + h) * a.W + w) * a.C + c0 + chunk * EPC) * sizeof(T));
-          inb |= 1u << i;
+        for (int i = 0; i < NX; ++i) {
+          const int t = KH * i + kh;
+          const int r = (t >= TS) + (t >= 2 * TS), s_ = t - r * TS;
+          if (t < TAPS && (unsigned)(h0 + r) < (unsigned)a.H && (unsigned)(w0 + s_) < (unsigned)a.W) {
+            xreg[i] = ld16(xp + (long)(r * a.W + s_) * (a.C * (int)sizeof(T)));
+            inb |= 1u << i;
+          }
+        }
+      } else {                                    // (the narrow form sits at the register limit: per-tap addresses from scratch)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int r = t / TS, s_ = t - r * TS;
+          const int h = ho * a.stride - a.pad + r, w = wo * a.stride - a.pad + s_;
+          if (h >= 0 && w >= 0 && h < a.H && w < a.W) {
+            xreg[t] = ld16(xg + ((size_t)((n * a.H + h) * a.W + w) * a.C + c0 + chunk * EPC) * sizeof(T));
+            inb |= 1u << t;
+          }
         }
       }
     }
