@@ -60,9 +60,16 @@ typedef struct sslcr_conv_desc {
   int par4;               /* stride-2 3x3 pad-1 dgrad (transposed = 1, pix_mul = 2, PH x PW = the even-sized input / 2): all four
                              output-parity classes in ONE launch (class = grid z; offsets and tap subsets derived in the kernel)
                              instead of four launches with pix_off / tap_mask.  DMA-gather kernel shapes only. */
+  /* Segments (models/net.py:50-66, TripletNet: three branches through ONE backbone, BatchNorm statistics per branch): with
+     seg_images > 0 the N images are N / seg_images independent batches in one launch -- segment s reads its prologue from
+     in_scale + s * seg_stride / in_shift + s * seg_stride, and the stats rows of segment s are rows
+     [s * rows / nseg, (s + 1) * rows / nseg) of sslcr_conv2d_partial_rows (no workgroup's rows mix segments).  Forward form only
+     (no mask_x); sslcr_conv2d fails where the kernel serving the shape has no segment form (sslcr_conv2d_segments_ok). */
+  int seg_images, seg_stride;
 } sslcr_conv_desc;
 int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream);
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d);
+int sslcr_conv2d_segments_ok(int dtype, const sslcr_conv_desc* d);      /* 1: this descriptor's seg_images is served */
 /* name of the kernel instance sslcr_conv2d would launch for this descriptor, spelled as rocprofv3 prints it (static string;
    lets tests and profiles tie a shape to the code path that serves it) */
 const char* sslcr_conv2d_kernel_name(int dtype, const sslcr_conv_desc* d);
@@ -152,7 +159,12 @@ typedef struct sslcr_bn_finalize_desc {
   float momentum, eps; int replay;    /* replay=3 reproduces TripletNet_Finetune's 3 identical passes (models/net.py:88-90) */
   double* sums_out;       /* [2][C]: only reduce the partial rows (sharded runs all-reduce this, then call again with sums_in) */
   const double* sums_in;
-  double* stage;          /* workspace [32][2][C] doubles for the two-stage row reduction */
+  double* stage;          /* workspace [32][2][C] doubles for the two-stage row reduction ([nseg][32][2][C] with segments) */
+  /* segments (sslcr_conv_desc.seg_images): nseg > 1 finalizes nseg BatchNorm batches in one call -- segment s owns partial rows
+     [s * rows / nseg, (s + 1) * rows / nseg) and writes scale / shift / mean / invstd at + s * seg_stride floats; the running
+     statistics take the nseg updates one after the other, segment 0 first, like nseg successive forward calls (count = elements
+     per channel of ONE segment).  Not with sums_out / sums_in. */
+  int nseg, seg_stride;
 } sslcr_bn_finalize_desc;
 int sslcr_bn_finalize(const sslcr_bn_finalize_desc* d, void* stream);
 
@@ -160,6 +172,7 @@ typedef struct sslcr_bn_act_desc {      /* y = relu(x*scale+shift [+ res*rscale+
   const void* x; const float* scale; const float* shift;
   const void* res; const float* rscale; const float* rshift;
   void* y; size_t pixels; int C; int relu;
+  int nseg, seg_stride;   /* nseg > 1: the pixels are nseg equal segments, segment s uses (r)scale / (r)shift + s * seg_stride */
 } sslcr_bn_act_desc;
 int sslcr_bn_act(int dtype, const sslcr_bn_act_desc* d, void* stream);
 
@@ -396,6 +409,9 @@ int sslcr_net_grad(sslcr_net* net, int param_index, float* out, void* stream);  
  *       11..14 bn1's saved scale, shift, mean, invstd (fp32 [C]; dims = {C,1,1,1})
  * out == NULL: only dims4 / flags are filled. */
 int sslcr_net_debug_tap(sslcr_net* net, int on);
+/* 1 when the last train-mode forward of a TripletNet ran its three branches as segments of one launch per layer
+ * (sslcr_conv_desc.seg_images; bf16, unsharded), 0 when it ran them pass by pass */
+int sslcr_net_segments_used(const sslcr_net* net);
 int sslcr_net_debug_tensor(sslcr_net* net, int block, int kind, void* out, size_t out_bytes, int* dims4, int* flags, void* stream);
 /* fused multi-tensor update of every requires_grad parameter; state1/state2 = per-parameter optimizer state
  * (exp_avg/exp_avg_sq or momentum_buffer) owned by the caller, NULL entries for frozen parameters */

@@ -27,7 +27,7 @@ ConvDesc = _S("ConvDesc", [("x", vp), ("w", vp), ("y", vp), ("in_scale", vp), ("
               [(k, i32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "PH", "PW", "OH", "OW", "osh",
                                   "transposed", "in_relu", "relu", "accumulate", "pix_mul", "pix_off_h", "pix_off_w")] +
               [("tap_mask", C.c_uint), ("mask_x", vp), ("mask_scale", vp), ("mask_shift", vp), ("mask_mean", vp),
-               ("par4", i32)])
+               ("par4", i32), ("seg_images", i32), ("seg_stride", i32)])
 WgradDesc = _S("WgradDesc", [("x", vp), ("dy", vp), ("dw", vp), ("in_scale", vp), ("in_shift", vp), ("in_relu", i32)] +
                [(k, i32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW", "seg_images", "seg_stride")])
 StemDesc = _S("StemDesc", [("x", vp), ("w", vp), ("y", vp), ("bias", vp), ("stats", vp)] +
@@ -38,9 +38,9 @@ BnFinalizeDesc = _S("BnFinalizeDesc", [("partials", vp), ("rows", i32), ("C", i3
                                        ("beta", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("invstd", vp),
                                        ("running_mean", vp), ("running_var", vp), ("num_batches_tracked", vp),
                                        ("momentum", f32), ("eps", f32), ("replay", i32), ("sums_out", vp),
-                                       ("sums_in", vp), ("stage", vp)])
+                                       ("sums_in", vp), ("stage", vp), ("nseg", i32), ("seg_stride", i32)])
 BnActDesc = _S("BnActDesc", [("x", vp), ("scale", vp), ("shift", vp), ("res", vp), ("rscale", vp), ("rshift", vp),
-                             ("y", vp), ("pixels", sz), ("C", i32), ("relu", i32)])
+                             ("y", vp), ("pixels", sz), ("C", i32), ("relu", i32), ("nseg", i32), ("seg_stride", i32)])
 PoolFwdDesc = _S("PoolFwdDesc", [("x", vp), ("scale", vp), ("shift", vp), ("y", vp), ("argmax", vp)] +
                  [(k, i32) for k in ("N", "H", "W", "C", "OH", "OW")])
 PoolBwdDesc = _S("PoolBwdDesc", [("dy", vp), ("argmax", vp), ("x", vp), ("scale", vp), ("shift", vp), ("dx", vp)] +
@@ -77,6 +77,7 @@ SIGNATURES = {
     "sslcr_last_error": (C.c_char_p, []),
     "sslcr_conv2d": (i32, [i32, P(ConvDesc), vp]),
     "sslcr_conv2d_partial_rows": (i32, [P(ConvDesc)]),
+    "sslcr_conv2d_segments_ok": (i32, [i32, P(ConvDesc)]),
     "sslcr_conv2d_kernel_name": (C.c_char_p, [i32, P(ConvDesc)]),
     "sslcr_conv2d_fp8": (i32, [P(ConvDesc), P(Fp8Desc), vp]),
     "sslcr_conv2d_fp8_partial_rows": (i32, [P(ConvDesc)]),

@@ -8,13 +8,16 @@
 namespace sslcr {
 
 // ------------------------------------------------------------------ statistics: partial rows -> sums -> scale/shift
-// stage 1: grid (C/32, SPLITS); block 256 = 32 channels x 8 row lanes
+// stage 1: grid (C/32, SPLITS, nseg); block 256 = 32 channels x 8 row lanes.  Segment z owns rows [z * rows, (z + 1) * rows) of
+// `part` and the z-th [splits][2][C] slab of `out` (rows = rows per segment)
 __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const float* __restrict__ part, int rows, int C, double* __restrict__ out, int splits) {
   __shared__ double sm[2][8][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   const int rl = threadIdx.x >> 5;
   const int per = (rows + splits - 1) / splits;
   const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  part += (size_t)blockIdx.z * rows * 2 * C;
+  out += (size_t)blockIdx.z * splits * 2 * C;
   double s = 0.0, ss = 0.0;
   if (c < C) {
     int r = r0 + rl;
@@ -44,49 +47,59 @@ __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const float* __rest
   }
 }
 
-// stage 2 (+ finalize): one thread per channel
+// stage 2 (+ finalize): one thread per channel; with segments (a.nseg > 1) the thread finalizes them one after the other, so the
+// running statistics see the updates in segment order -- the order of the reference's successive forward calls
 __global__ void bn_finalize_kernel(const double* __restrict__ stage, int splits, const BnFinalizeArgs a) {
   // 8 lanes per channel share the split rows (a serial loop over 32 splits is 64 dependent loads = 10 us per BatchNorm)
   const int c = blockIdx.x * (blockDim.x / 8) + (threadIdx.x >> 3);
   const int part = threadIdx.x & 7;
   const int cc = c < a.C ? c : a.C - 1;
-  double s = 0.0, ss = 0.0;
-  if (a.sums_in) {
-    s = a.sums_in[cc];
-    ss = a.sums_in[a.C + cc];
-  } else {
-    for (int i = part; i < splits; i += 8) {
-      s += stage[((size_t)i * 2) * a.C + cc];
-      ss += stage[((size_t)i * 2 + 1) * a.C + cc];
-    }
+  const int nseg = a.nseg > 1 ? a.nseg : 1;
+  float rm = 0.f, rv = 0.f;
+  const bool lead = c < a.C && part == 0;
+  if (lead && a.running_mean) { rm = a.running_mean[c]; rv = a.running_var[c]; }
+  for (int z = 0; z < nseg; ++z) {
+    double s = 0.0, ss = 0.0;
+    if (a.sums_in) {
+      s = a.sums_in[cc];
+      ss = a.sums_in[a.C + cc];
+    } else {
+      const double* stz = stage + (size_t)z * splits * 2 * a.C;
+      for (int i = part; i < splits; i += 8) {
+        s += stz[((size_t)i * 2) * a.C + cc];
+        ss += stz[((size_t)i * 2 + 1) * a.C + cc];
+      }
 #pragma unroll
-    for (int m = 1; m < 8; m <<= 1) { s += __shfl_xor(s, m); ss += __shfl_xor(ss, m); }
-  }
-  if (c >= a.C || part != 0) return;
-  if (a.sums_out) {
-    a.sums_out[c] = s;
-    a.sums_out[a.C + c] = ss;
-    return;
-  }
-  const double mean = s / a.count;
-  double var = ss / a.count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const double invstd = 1.0 / sqrt(var + (double)a.eps);
-  const double sc = (double)a.gamma[c] * invstd;
-  a.scale[c] = (float)sc;
-  a.shift[c] = (float)((double)a.beta[c] - mean * sc);
-  if (a.mean) a.mean[c] = (float)mean;
-  if (a.invstd) a.invstd[c] = (float)invstd;
-  if (a.running_mean) {
-    const double unb = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
-    float rm = a.running_mean[c], rv = a.running_var[c];
-    for (int i = 0; i < a.replay; ++i) {       // same arithmetic as `replay` sequential nn.BatchNorm2d updates
-      rm = (1.f - a.momentum) * rm + a.momentum * (float)mean;
-      rv = (1.f - a.momentum) * rv + a.momentum * (float)unb;
+      for (int m = 1; m < 8; m <<= 1) { s += __shfl_xor(s, m); ss += __shfl_xor(ss, m); }
     }
+    if (!lead) continue;
+    if (a.sums_out) {
+      a.sums_out[c] = s;
+      a.sums_out[a.C + c] = ss;
+      return;
+    }
+    const size_t so = (size_t)z * a.seg_stride;
+    const double mean = s / a.count;
+    double var = ss / a.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    const double sc = (double)a.gamma[c] * invstd;
+    a.scale[so + c] = (float)sc;
+    a.shift[so + c] = (float)((double)a.beta[c] - mean * sc);
+    if (a.mean) a.mean[so + c] = (float)mean;
+    if (a.invstd) a.invstd[so + c] = (float)invstd;
+    if (a.running_mean) {
+      const double unb = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+      for (int i = 0; i < a.replay; ++i) {       // same arithmetic as `replay` sequential nn.BatchNorm2d updates
+        rm = (1.f - a.momentum) * rm + a.momentum * (float)mean;
+        rv = (1.f - a.momentum) * rv + a.momentum * (float)unb;
+      }
+    }
+  }
+  if (lead && a.running_mean) {
     a.running_mean[c] = rm;
     a.running_var[c] = rv;
-    if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += a.replay;
+    if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += (int64_t)a.replay * nseg;
   }
 }
 
@@ -94,11 +107,14 @@ hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
   constexpr int SPLITS = 32;
   double* stage = a.stage;
   int splits = 0;
+  const int nseg = a.nseg > 1 ? a.nseg : 1;
+  if (nseg > 1 && (a.sums_in || a.sums_out || a.rows % nseg != 0)) return hipErrorInvalidValue;
   if (!a.sums_in) {
-    splits = a.rows / 32;                       // >= 4 dependent row loads per thread before it is worth another block row
+    const int rows = a.rows / nseg;             // per segment
+    splits = rows / 32;                         // >= 4 dependent row loads per thread before it is worth another block row
     if (splits > SPLITS) splits = SPLITS;
     if (splits < 1) splits = 1;
-    hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(cdiv(a.C, 32), splits), dim3(256), 0, st, a.partials, a.rows, a.C, stage, splits);
+    hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(cdiv(a.C, 32), splits, nseg), dim3(256), 0, st, a.partials, rows, a.C, stage, splits);
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a.C, 32)), dim3(256), 0, st, stage, splits, a);
   return hipGetLastError();
@@ -109,17 +125,20 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
   constexpr int EPC = Elem<T>::EPC;
   const int cols = a.C / EPC;
-  const size_t total = a.pixels * cols;
-  const char* x = reinterpret_cast<const char*>(a.x);
-  const char* r = reinterpret_cast<const char*>(a.res);
-  char* y = reinterpret_cast<char*>(a.y);
+  // segments (sslcr_bn_act_desc.nseg): grid y = segment, an equal share of the pixels with its own constants
+  const int nseg = a.nseg > 1 ? a.nseg : 1;
+  const size_t total = a.pixels / nseg * cols;
+  const size_t seg_bytes = total * 16 * blockIdx.y, so = (size_t)blockIdx.y * a.seg_stride;
+  const char* x = reinterpret_cast<const char*>(a.x) + seg_bytes;
+  const char* r = a.res ? reinterpret_cast<const char*>(a.res) + seg_bytes : nullptr;
+  char* y = reinterpret_cast<char*>(a.y) + seg_bytes;
   // grid stride is a multiple of cols: the thread's EPC channels (and their constants) are fixed for the whole loop
   const int cb = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % cols) * EPC;
   float sc[EPC], sh[EPC], rsc[EPC], rsh[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
-    sc[e] = a.scale[cb + e]; sh[e] = a.shift[cb + e];
-    rsc[e] = a.rscale ? a.rscale[cb + e] : 1.f; rsh[e] = a.rscale ? a.rshift[cb + e] : 0.f;
+    sc[e] = a.scale[so + cb + e]; sh[e] = a.shift[so + cb + e];
+    rsc[e] = a.rscale ? a.rscale[so + cb + e] : 1.f; rsh[e] = a.rscale ? a.rshift[so + cb + e] : 0.f;
   }
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float f[EPC], g[EPC];
@@ -150,10 +169,13 @@ static inline int ew_grid(size_t work_items) {
 }
 
 hipError_t launch_bn_act(int dtype, const BnActArgs& a, hipStream_t st) {
+  const int nseg = a.nseg > 1 ? a.nseg : 1;
+  if (a.pixels % nseg != 0) return hipErrorInvalidValue;
+  const size_t per = a.pixels / nseg;
   if (dtype == DT_BF16) {
-    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(ew_grid(a.pixels * (a.C / 8))), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_act_kernel<bf16_t>, dim3(ew_grid(per * (a.C / 8)), nseg), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_grid(a.pixels * (a.C / 4))), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_grid(per * (a.C / 4)), nseg), dim3(256), 0, st, a);
   }
   return hipGetLastError();
 }

@@ -40,9 +40,11 @@ int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream) {
   NEED(d->C % (dtype == SSLCR_BF16 ? 64 : 32) == 0, "C must be a multiple of the 128-byte channel slab");
   NEED(d->K % 64 == 0, "K % 64");
   NEED(d->osh >= 1 && d->PH > 0 && d->PW > 0, "pixel space");
+  NEED(conv_segments_ok(dtype, *d), "seg_images: no segment form for this shape / dtype (sslcr_conv2d_segments_ok)");
   return check(launch_conv(dtype, *d, (hipStream_t)stream), "conv2d");
 }
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d) { return d ? conv_partials_rows(*d) : -1; }
+int sslcr_conv2d_segments_ok(int dtype, const sslcr_conv_desc* d) { return (d && (dtype == DT_F32 || dtype == DT_BF16) && conv_segments_ok(dtype, *d)) ? 1 : 0; }
 const char* sslcr_conv2d_kernel_name(int dtype, const sslcr_conv_desc* d) { return d ? conv_kernel_name(dtype, *d) : ""; }
 
 int sslcr_conv2d_fp8(const sslcr_conv_desc* d, const sslcr_fp8_desc* q, void* stream) {

@@ -102,8 +102,18 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   const int g = lane >> 4, li = lane & 15;
   const int wp = wave & 3, wk = wave >> 2;
   const int tiles_w = a.W / TW, tiles_h = a.H / TH;
-  if (XF)
-    for (int c = tid; c < a.C; c += NT) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
+  // segments (sslcr_conv_desc.seg_images): the grid is nseg equal groups of workgroups, group s walks the tiles of images
+  // [s * seg_images, (s + 1) * seg_images) with that segment's prologue -- tiles_total / n_items are then PER SEGMENT.  A
+  // workgroup's four statistics rows (index blockIdx.x * 4 + ...) therefore belong to one segment.
+  const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
+  const int G = gridDim.x / nseg;
+  const int seg = nseg > 1 ? (int)blockIdx.x / G : 0, lb = (int)blockIdx.x - seg * G;
+  const int seg_n0 = seg * a.seg_images;
+  if (XF) {
+    const float* isc = a.in_scale + (size_t)seg * a.seg_stride;
+    const float* ish = a.in_shift + (size_t)seg * a.seg_stride;
+    for (int c = tid; c < a.C; c += NT) { s_scale[c] = isc[c]; s_shift[c] = ish[c]; }
+  }
   for (int i = tid; i < 8 * BKO; i += NT) s_stat[i] = 0.f;
   // the (folded-BatchNorm) bias of all K outputs: read from LDS in the epilogue.  As global loads -- even skipped ones, when
   // there is no bias -- they put a compiler vmcnt(0) in front of the output stores
@@ -120,8 +130,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
 
   // XCD-aware walk: blocks land on XCD (blockIdx % 8); each XCD takes a contiguous run of tiles per round so that
   // neighbouring tiles' shared halo rows hit the same L2.
-  const int G = gridDim.x;
-  const int first = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+  const int first = (G & 7) ? lb : (lb & 7) * (G >> 3) + (lb >> 3);
   if (first >= n_items) return;
 
   // ---- per-thread staging roles, fixed for the whole walk
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
     int t = q.tile;
     const int tw_i = t % tiles_w; t /= tiles_w;
     const int th_i = t % tiles_h;
-    q.n0 = t / tiles_h;
+    q.n0 = t / tiles_h + seg_n0;
     q.h0 = th_i * TH; q.w0 = tw_i * TW;
     q.origin = (q.n0 * a.H + q.h0) * a.W + q.w0;
     q.out = (unsigned long long)((q.h0 == 0) | ((q.h0 + TH >= a.H) << 1) | ((q.w0 == 0) << 2) | ((q.w0 + TW >= a.W) << 3)) *
@@ -540,10 +549,16 @@ bool conv_h16_ok(int dtype, const ConvArgs& a) {
   return conv_halo256_mode(dtype, a) == 16 && conv_halo256_mode(DT_BF16, a) == 16;
 }
 // partial-statistics rows the launch will write: four per workgroup (see s_stat)
+// workgroups of the launch: one per CU, or per item where there are fewer; with segments, nseg equal groups
+static int h16_grid(const ConvArgs& a, int bko) {
+  const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
+  const int n_items = (a.N / nseg) * (a.H / 16) * (a.W / 16) * (a.K / bko);       // per segment
+  const int per = device_cus() / nseg;
+  return (n_items < per ? n_items : per) * nseg;
+}
 int conv_h16_rows(const ConvArgs& a) {
-  const int bko = a.K % 128 == 0 ? 128 : 64;
-  const int n_items = a.N * (a.H / 16) * (a.W / 16) * (a.K / bko);
-  return (n_items < device_cus() ? n_items : device_cus()) * 4;
+  if (a.seg_images > 0 && conv_pp64_ok(DT_BF16, a)) return conv_pp64_rows(a);      // segments are bf16-only: the ping-pong kernel's own grid
+  return h16_grid(a, a.K % 128 == 0 ? 128 : 64) * 4;
 }
 
 // bf16 64 -> 64: one 128-byte slab of input channels and one kout block, the filter bank fits LDS whole
@@ -561,9 +576,10 @@ static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int tiles = a.N * (a.H / 16) * (a.W / 16);
+  const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
+  const int tiles = (a.N / nseg) * (a.H / 16) * (a.W / 16);             // per segment, like n_items
   const int n_items = tiles * (a.K / BKO);
-  const int grid = n_items < device_cus() ? n_items : device_cus();     // one 8-wave workgroup per CU
+  const int grid = h16_grid(a, BKO);                                    // one 8-wave workgroup per CU
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WK), lds, st, a, tiles, n_items);
   return hipGetLastError();
 }

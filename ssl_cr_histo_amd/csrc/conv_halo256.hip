@@ -63,8 +63,11 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
   const int h0 = th_i * TH, w0 = tw_i * TW;
   const int k0 = blockIdx.y * BKO;
   const bool xform = a.in_scale != nullptr;
-  if (xform)
-    for (int c = tid; c < a.C; c += NT) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
+  if (xform) {
+    // segments (sslcr_conv_desc.seg_images): a tile's NI images sit in one segment (seg_images % NI == 0, conv_segments_ok)
+    const size_t so = a.seg_images > 0 ? (size_t)(n0 / a.seg_images) * a.seg_stride : 0;
+    for (int c = tid; c < a.C; c += NT) { s_scale[c] = a.in_scale[so + c]; s_shift[c] = a.in_shift[so + c]; }
+  }
 
   const int chunk = tid & 7;
   int src_off[NLD];

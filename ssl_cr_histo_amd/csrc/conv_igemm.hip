@@ -329,7 +329,26 @@ const char* conv_kernel_name(int dtype, const ConvArgs& a) {
   return bf ? "sslcr::conv_igemm_kernel<unsigned short, 64, 64>" : "sslcr::conv_igemm_kernel<float, 64, 64>";
 }
 
+// Segments (sslcr_conv_desc.seg_images): which kernels have the form, and where the row ranges come out right.
+//   conv3x3_h16 / conv3x3_pp64: the grid is split into nseg groups of workgroups (their statistics rows are per workgroup)
+//   conv3x3_halo256: one workgroup per tile, rows in tile order; a tile's images must not straddle a segment
+//   conv_dma: rows in pixel order, no prologue; a pixel block must not straddle a segment
+bool conv_segments_ok(int dtype, const ConvArgs& a) {
+  if (a.seg_images <= 0) return true;
+  if (dtype != DT_BF16 || a.N % a.seg_images != 0 || a.mask_x || a.transposed || a.par4) return false;
+  const int nseg = a.N / a.seg_images;
+  if (nseg > 8) return false;
+  if (conv_h16_ok(dtype, a)) return true;
+  const int q = conv_halo256_mode(dtype, a);
+  if (q) return q == 16 || a.seg_images % 4 == 0;
+  if (conv_halo_tw(dtype, a)) return false;
+  const int bp = conv_dma_bp(dtype, a);
+  if (bp) return !a.in_scale && ((long)a.seg_images * a.PH * a.PW) % bp == 0;
+  return false;
+}
+
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
+  if (!conv_segments_ok(dtype, a)) return hipErrorInvalidValue;
   if (conv_h16_ok(dtype, a)) return launch_conv_h16(dtype, a, st);
   if (a.mask_x) return hipErrorInvalidValue;        // the BatchNorm-backward front end exists in the 16x16-tile kernel only
   const int q = conv_halo256_mode(dtype, a);

@@ -88,9 +88,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
   float* s_stat = s_f + 320 + grp * 512;               // this group's [4 wave rows][2][64] partial (sum, sumsq)
 
   const int tiles_w = a.W / TW, tiles_h = a.H / TH;
-  const int G = gridDim.x;
+  // segments (sslcr_conv_desc.seg_images): nseg equal groups of workgroups, group s walks the tiles of its own images with its
+  // own prologue; tiles_total is then PER SEGMENT and a workgroup's statistics rows belong to one segment (conv_h16.hip)
+  const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
+  const int G = gridDim.x / nseg;
+  const int seg = nseg > 1 ? (int)blockIdx.x / G : 0, lb = (int)blockIdx.x - seg * G;
+  const int seg_n0 = seg * a.seg_images;
   // XCD-aware walk (blocks land on XCD blockIdx % 8): each XCD takes a contiguous run of tiles per round
-  const int vb = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+  const int vb = (G & 7) ? lb : (lb & 7) * (G >> 3) + (lb >> 3);
   const int first0 = 2 * vb;
   if (first0 >= tiles_total) return;
   const int nst = (tiles_total - first0 + 2 * G - 1) / (2 * G);       // stages of group 0 (group 1 may have one live stage less)
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
       __builtin_amdgcn_global_load_lds((gptr_pp)(wg + (size_t)tt * 64 * sizeof(T)), (lptr_pp)(s_w + tt * WBUF + (wave * 8) * 128), 16, 0, 0);
   }
   if (tid < 64) {
-    if (XF) { s_scale[tid] = a.in_scale[tid]; s_shift[tid] = a.in_shift[tid]; }
+    if (XF) { s_scale[tid] = a.in_scale[(size_t)seg * a.seg_stride + tid]; s_shift[tid] = a.in_shift[(size_t)seg * a.seg_stride + tid]; }
     s_bias[tid] = mk ? a.mask_scale[tid] : (a.bias ? a.bias[tid] : 0.f);
     if (mk) { s_msh[tid] = a.mask_shift[tid]; s_mmu[tid] = a.mask_mean[tid]; }
   }
@@ -151,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
     int t = tile;
     const int tw_i = t % tiles_w; t /= tiles_w;
     const int th_i = t % tiles_h;
-    q.n0 = t / tiles_h;
+    q.n0 = t / tiles_h + seg_n0;
     q.h0 = th_i * TH; q.w0 = tw_i * TW;
     q.origin = (q.n0 * a.H + q.h0) * a.W + q.w0;
     q.out = (unsigned long long)((q.h0 == 0) | ((q.h0 + TH >= a.H) << 1) | ((q.w0 == 0) << 2) | ((q.w0 + TW >= a.W) << 3)) *
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
     // not own are zeroed
     const int rw = tid >> 6, c = tid & 63;                 // rw = wave row * 2 + (0: sum, 1: sumsq)
     a.stats[((size_t)((int)blockIdx.x * 4 + (rw >> 1)) * 2 + (rw & 1)) * 64 + c] = s_f[320 + tid] + s_f[320 + 512 + tid];
-    const int eb = (int)blockIdx.x + G;
+    const int eb = (int)blockIdx.x + (int)gridDim.x;
     if (eb * 4 < rows_total) a.stats[((size_t)(eb * 4 + (rw >> 1)) * 2 + (rw & 1)) * 64 + c] = 0.f;
   }
 }
@@ -436,9 +441,10 @@ static int pp_cus() {
   return cus;
 }
 static int pp64_grid(const ConvArgs& a) {
-  const int tiles = a.N * (a.H / 16) * (a.W / 16);
-  const int pairs = (tiles + 1) / 2;
-  return pairs < pp_cus() ? pairs : pp_cus();
+  const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
+  const int tiles = (a.N / nseg) * (a.H / 16) * (a.W / 16);       // per segment
+  const int pairs = (tiles + 1) / 2, per = pp_cus() / nseg;
+  return (pairs < per ? pairs : per) * nseg;
 }
 
 // bf16 64 -> 64 on 16x16-tileable maps, every operand combination conv3x3_h16's resident-filter form serves (its caller has
@@ -450,7 +456,10 @@ bool conv_pp64_ok(int dtype, const ConvArgs& a) {
   return on && dtype == DT_BF16 && a.C == 64 && a.K == 64 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && !a.transposed &&
          a.H % 16 == 0 && a.W % 16 == 0 && !(a.in_scale && (a.residual || a.mask_x));
 }
-static int pp64_rows(const ConvArgs& a) {                 // == conv_h16_rows for this shape (one 64-kout block)
+// rows of a.stats: what conv3x3_h16 would write for this shape (one 64-kout block; the caller sized the buffer before it knew the
+// dtype); with segments -- a bf16-only form -- exactly this grid's rows, so that segment s owns rows [s, s + 1) * rows / nseg
+int conv_pp64_rows(const ConvArgs& a) {
+  if (a.seg_images > 0) return pp64_grid(a) * 4;
   const int tiles = a.N * (a.H / 16) * (a.W / 16);
   return (tiles < pp_cus() ? tiles : pp_cus()) * 4;
 }
@@ -467,10 +476,11 @@ hipError_t launch_conv_pp64(const ConvArgs& a, hipStream_t st) {
     }
     attr_done = true;
   }
-  const int tiles = a.N * (a.H / 16) * (a.W / 16);
+  const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
+  const int tiles = (a.N / nseg) * (a.H / 16) * (a.W / 16);       // per segment
   const int grid = pp64_grid(a);
   if (a.mask_x && !a.stats) return hipErrorInvalidValue;
-  const int rows = pp64_rows(a);
+  const int rows = conv_pp64_rows(a);
   if (a.in_scale) hipLaunchKernelGGL((conv3x3_pp64_kernel<true, 0>), dim3(grid), dim3(512), lds, st, a, tiles, rows);
   else if (a.mask_x) hipLaunchKernelGGL((conv3x3_pp64_kernel<false, 2>), dim3(grid), dim3(512), lds, st, a, tiles, rows);
   else if (a.residual) hipLaunchKernelGGL((conv3x3_pp64_kernel<false, 1>), dim3(grid), dim3(512), lds, st, a, tiles, rows);

@@ -219,6 +219,7 @@ struct sslcr_net {
   float *cat[3], *hact[3], *fi[3], *feats = nullptr, *hid = nullptr, *logits = nullptr, *dE[3], *dfeats = nullptr, *dhid = nullptr,
         *dtmp256 = nullptr, *dtmp512 = nullptr, *dcat = nullptr, *scratch = nullptr, *dlogits = nullptr, *logits_t = nullptr;
   int last_N = 0, last_npass = 0;
+  bool last_segments = false;      // the last train forward ran the branches as segments
   bool packed_train = false, packed_eval = false;
   // sslcr_net_debug_tap: backward keeps copies of each block's transient gradient tensors (pass 0) for the layer-wise replay test
   bool tap = false;
@@ -364,6 +365,7 @@ hipError_t prof_wgrad(sslcr_ctx* c, int dt, const WgradArgs& a, hipStream_t st) 
   return e;
 }
 
+constexpr int kMaxSeg = 3;      // TripletNet branches run as segments of one launch (backbone_forward_train_segments)
 const int kBlockCfg[8][3] ={{64, 64, 1}, {64, 64, 1}, {64, 128, 2}, {128, 128, 1}, {128, 256, 2}, {256, 256, 1}, {256, 512, 2}, {512, 512, 1}};
 
 inline int out_dim(int h, int k, int stride, int pad) { return (h + 2 * pad - k) / stride + 1; }
@@ -516,11 +518,15 @@ int pack_conv_layer(sslcr_net* n, ConvL& L, const BnL& bn, int mode, hipStream_t
 }
 
 // ---------------------------------------------------------------- BN finalize (optionally synced across ranks)
-int finalize_bn(sslcr_net* n, const BnL& bn, const float* partials, int rows, double local_count, BnSaved& sv, int replay, hipStream_t st) {
+// nseg > 1: `rows` covers nseg segments (equal shares, in order), sv is segment 0's and the others follow seg_stride floats apart
+int finalize_bn(sslcr_net* n, const BnL& bn, const float* partials, int rows, double local_count, BnSaved& sv, int replay, hipStream_t st,
+                int nseg = 1, int seg_stride = 0) {
   sslcr_ctx* c = n->ctx;
   BnFinalizeArgs a;
   memset(&a, 0, sizeof(a));
   a.partials = partials; a.rows = rows; a.C = bn.C;
+  a.nseg = nseg; a.seg_stride = seg_stride;
+  if (nseg > 1 && sharded(c) && c->bn_sync) return fail("finalize_bn: segments with synced BatchNorm");
   a.gamma = n->params[bn.pg]; a.beta = n->params[bn.pb];
   a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
   a.running_mean = n->bn_rm[bn.bidx]; a.running_var = n->bn_rv[bn.bidx]; a.num_batches_tracked = n->bn_nbt[bn.bidx];
@@ -673,6 +679,106 @@ int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f3
     X = ps.blk[i].y; xh = oh; xw = ow;
   }
   TRY(launch_avgpool_fwd(dt, X, ps.E, N, xh * xw, 512, st));
+  return 0;
+}
+
+// The TripletNet branches (models/net.py:50-66: three tiles through ONE backbone, BatchNorm statistics per call) as SEGMENTS of one
+// launch per layer: the saved tensors of the passes are contiguous (alloc_passes), so a conv over 3N images with
+// sslcr_conv_desc.seg_images = N writes all three, its statistics rows split by segment, and one finalize / one bn_act serves the
+// three BatchNorm batches (running statistics updated in branch order).  At N = 128 per branch the per-pass launches were 60 %
+// slower per image than the same kernels at N = 640 (r03: conv3x3_h16 48.7 us against 149 us for five times the images).
+// The stem (three separate input tensors) and its pool stay per pass.  false = some layer has no segment form here: the caller
+// runs the passes one by one.
+bool segments_servable(sslcr_net* n, int N, int H, int W) {
+  sslcr_ctx* c = n->ctx;
+  static const bool on = [] { const char* e = getenv("SSLCR_SEGMENTS"); return !(e && e[0] == '0'); }();
+  if (!on || !n->triplet || c->dtype != DT_BF16 || c->fp8 || (sharded(c) && c->bn_sync) || c->prof.on) return false;
+  const Dims d = make_dims(H, W);
+  int xh = d.ph, xw = d.pw;
+  for (int i = 0; i < 8; ++i) {
+    BlockL& B = n->blocks[i];
+    const int oh = d.lh[i], ow = d.lw[i];
+    ConvArgs a1 = conv_args(B.c1, nullptr, nullptr, nullptr, 3 * N, xh, xw);
+    a1.seg_images = N;
+    ConvArgs a2 = conv_args(B.c2, nullptr, nullptr, nullptr, 3 * N, oh, ow);
+    a2.seg_images = N; a2.in_scale = c->ones; a2.in_shift = c->zeros;
+    if (!conv_segments_ok(c->dtype, a1) || !conv_segments_ok(c->dtype, a2)) return false;
+    if (B.has_ds) {
+      ConvArgs ad = conv_args(B.ds, nullptr, nullptr, nullptr, 3 * N, xh, xw);
+      ad.seg_images = N;
+      if (!conv_segments_ok(c->dtype, ad)) return false;
+    }
+    if (conv_partials_rows(a1) % 3 || conv_partials_rows(a2) % 3) return false;
+    xh = oh; xw = ow;
+  }
+  return true;
+}
+
+int backbone_forward_train_segments(sslcr_net* n, const void* const* xs, int in_f32, int N, int H, int W, hipStream_t st) {
+  sslcr_ctx* c = n->ctx;
+  const int dt = c->dtype;
+  constexpr int NS = 3;
+  if (n->pass[0].N != N || n->pass[0].H != H || n->pass[0].W != W || !n->pass[0].mem.p) TRYI(alloc_passes(n, NS, N, H, W));
+  const Dims d = make_dims(H, W);
+  const int seg_stride = (int)(((char*)n->pass[1].bn[0].scale - (char*)n->pass[0].bn[0].scale) / sizeof(float));
+  for (int p = 0; p < NS; ++p) {
+    PassState& ps = n->pass[p];
+    ps.x = xs[p]; ps.in_f32 = in_f32; ps.x2 = nullptr; ps.n_split = 0;
+    StemArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = xs[p]; a.w = n->stem.w_fwd; a.y = ps.raw0;
+    a.N = N; a.H = H; a.W = W; a.OH = d.oh0; a.OW = d.ow0; a.in_f32 = in_f32;
+    const int rows = stem_partials_rows(a);
+    TRYI(c->partials.ensure((size_t)rows * 2 * 64 * sizeof(float)));
+    a.stats = (float*)c->partials.p;
+    TRY(launch_stem(dt, a, st));
+    TRYI(finalize_bn(n, n->bn0, a.stats, rows, (double)N * d.oh0 * d.ow0, ps.bn[0], 1, st));
+    PoolFwdArgs q;
+    memset(&q, 0, sizeof(q));
+    q.x = ps.raw0; q.scale = ps.bn[0].scale; q.shift = ps.bn[0].shift; q.y = ps.pooled; q.argmax = ps.argmax;
+    q.N = N; q.H = d.oh0; q.W = d.ow0; q.C = 64; q.OH = d.ph; q.OW = d.pw;
+    TRY(launch_bn_relu_maxpool(dt, q, st));
+  }
+  PassState& p0 = n->pass[0];                  // the first segment's tensors; the others follow contiguously
+  const char* X = p0.pooled;
+  int xh = d.ph, xw = d.pw;
+  for (int i = 0; i < 8; ++i) {
+    BlockL& B = n->blocks[i];
+    const int oh = d.lh[i], ow = d.lw[i];
+    float* part; int rows;
+    ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fwd, p0.blk[i].raw1, NS * N, xh, xw);
+    a1.seg_images = N;
+    TRYI(ensure_partials(c, a1, &part, &rows));
+    a1.stats = part;
+    TRY(prof_conv(c, dt, a1, st));
+    TRYI(finalize_bn(n, B.b1, part, rows, (double)N * oh * ow, p0.bn[B.b1.bidx], 1, st, NS, seg_stride));
+    ConvArgs a2 = conv_args(B.c2, p0.blk[i].raw1, B.c2.w_fwd, p0.blk[i].raw2, NS * N, oh, ow);
+    a2.in_scale = p0.bn[B.b1.bidx].scale; a2.in_shift = p0.bn[B.b1.bidx].shift; a2.in_relu = 1;
+    a2.seg_images = N; a2.seg_stride = seg_stride;
+    TRYI(ensure_partials(c, a2, &part, &rows));
+    a2.stats = part;
+    TRY(prof_conv(c, dt, a2, st));
+    TRYI(finalize_bn(n, B.b2, part, rows, (double)N * oh * ow, p0.bn[B.b2.bidx], 1, st, NS, seg_stride));
+    BnActArgs e;
+    memset(&e, 0, sizeof(e));
+    e.x = p0.blk[i].raw2; e.scale = p0.bn[B.b2.bidx].scale; e.shift = p0.bn[B.b2.bidx].shift;
+    e.y = p0.blk[i].y; e.pixels = (size_t)NS * N * oh * ow; e.C = B.c2.cout; e.relu = 1;
+    e.nseg = NS; e.seg_stride = seg_stride;
+    if (B.has_ds) {
+      ConvArgs ad = conv_args(B.ds, X, B.ds.w_fwd, p0.blk[i].rawd, NS * N, xh, xw);
+      ad.seg_images = N;
+      TRYI(ensure_partials(c, ad, &part, &rows));
+      ad.stats = part;
+      TRY(prof_conv(c, dt, ad, st));
+      TRYI(finalize_bn(n, B.bd, part, rows, (double)N * oh * ow, p0.bn[B.bd.bidx], 1, st, NS, seg_stride));
+      e.res = p0.blk[i].rawd; e.rscale = p0.bn[B.bd.bidx].scale; e.rshift = p0.bn[B.bd.bidx].shift;
+    } else {
+      e.res = X;
+    }
+    TRY(launch_bn_act(dt, e, st));
+    X = p0.blk[i].y; xh = oh; xw = ow;
+  }
+  TRY(launch_avgpool_fwd(dt, X, p0.E, NS * N, xh * xw, 512, st));
   return 0;
 }
 
@@ -1222,7 +1328,13 @@ int net_forward(sslcr_net* n, int train, const void* const* xs, int in_f32, int 
   const int npass = n->triplet ? 3 : 1;
   TRYI(alloc_heads(n, N));
   float* E[3] = {nullptr, nullptr, nullptr};
-  for (int i = 0; i < npass; ++i) {
+  const bool segs = train && npass == 3 && segments_servable(n, N, H, W);
+  if (train) n->last_segments = segs;
+  if (segs) {
+    TRYI(backbone_forward_train_segments(n, xs, in_f32, N, H, W, st));
+    for (int i = 0; i < npass; ++i) E[i] = n->pass[i].E;
+  }
+  for (int i = 0; i < npass && !segs; ++i) {
     if (train) {
       TRYI(backbone_forward_train(n, n->pass[i], xs[i], in_f32, N, H, W, n->triplet ? 1 : 3, st));
       E[i] = n->pass[i].E;
@@ -1275,9 +1387,10 @@ int sslcr_create(sslcr_ctx** out, int device, int dtype) {
   sslcr_ctx* c = new sslcr_ctx();
   c->device = device; c->dtype = dtype == SSLCR_FP8 ? SSLCR_BF16 : dtype; c->fp8 = dtype == SSLCR_FP8;
   if (const char* e = getenv("SSLCR_FUSE_STEM_BWD")) c->fuse_stem_bwd = atoi(e) != 0;
-  if (c->small.ensure(32 * 2 * 512 * sizeof(double) + 2 * 2 * 512 * sizeof(double) + 2 * 512 * sizeof(float)) != 0) { delete c; return -1; }
+  // bn_stage: [kMaxSeg][32][2][C] (sslcr_bn_finalize_desc.stage with segments)
+  if (c->small.ensure((size_t)kMaxSeg * 32 * 2 * 512 * sizeof(double) + 2 * 2 * 512 * sizeof(double) + 2 * 512 * sizeof(float)) != 0) { delete c; return -1; }
   c->bn_stage = (double*)c->small.p;
-  c->bn_sums = c->bn_stage + 32 * 2 * 512;        // two [2][C] slots (bn2 + projection BatchNorm of a block share an all-reduce)
+  c->bn_sums = c->bn_stage + (size_t)kMaxSeg * 32 * 2 * 512;        // two [2][C] slots (bn2 + projection BatchNorm of a block share an all-reduce)
   c->ones = (float*)(c->bn_sums + 2 * 2 * 512);
   c->zeros = c->ones + 512;
   TRY(launch_fill(c->ones, 512, 1.f, nullptr));
@@ -1526,6 +1639,7 @@ int sslcr_net_backward(sslcr_net* n, const float* dlogits, void* stream) {
   return net_backward(n, dlogits, (hipStream_t)stream);
 }
 
+int sslcr_net_segments_used(const sslcr_net* n) { return (n && n->last_segments) ? 1 : 0; }
 int sslcr_net_debug_tap(sslcr_net* n, int on) {
   if (!n) return fail("sslcr_net_debug_tap: null net");
   n->tap = on != 0;

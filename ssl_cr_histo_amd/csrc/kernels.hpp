@@ -28,6 +28,7 @@ int conv_tile_bp(const ConvArgs& a);
 const char* conv_kernel_name(int dtype, const ConvArgs& a);
 const char* wgrad_kernel_name(int dtype, const WgradArgs& a);
 int conv_partials_rows(const ConvArgs& a);
+bool conv_segments_ok(int dtype, const ConvArgs& a);
 // conv_halo.hip
 int conv_halo_tw(int dtype, const ConvArgs& a);
 int conv_halo_tiles(const ConvArgs& a, int tw);
@@ -45,6 +46,7 @@ const char* conv_h16_name(int dtype, const ConvArgs& a);
 bool conv_pp64_ok(int dtype, const ConvArgs& a);
 hipError_t launch_conv_pp64(const ConvArgs& a, hipStream_t st);
 const char* conv_pp64_name(const ConvArgs& a);
+int conv_pp64_rows(const ConvArgs& a);
 // conv_dma.hip
 int conv_dma_bp(int dtype, const ConvArgs& a);
 int conv_dma_rows(const ConvArgs& a, int bp);

@@ -52,6 +52,7 @@ _ENGINE_SIGS = {
     "sslcr_net_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "sslcr_net_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "sslcr_net_debug_tap": (C.c_int, [C.c_void_p, C.c_int]),
+    "sslcr_net_segments_used": (C.c_int, [C.c_void_p]),
     "sslcr_net_debug_tensor": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.c_void_p]),
     "sslcr_net_optimizer_step": (C.c_int, [C.c_void_p, C.POINTER(L.OptDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
@@ -165,6 +166,11 @@ class BoundNet:
         out = torch.empty_like(self.params[index])
         L.check(L.lib().sslcr_net_grad(self.handle, index, L.ptr(out), L.stream_ptr()))
         return out
+
+    @property
+    def segments_used(self):
+        """True when the last train-mode forward ran the TripletNet branches as segments of one launch per layer."""
+        return bool(L.lib().sslcr_net_segments_used(self.handle))
 
     def debug_tap(self, on):
         """keep copies of every block's transient gradient tensors in backward (layer-wise parity test; see include/sslcr.h)."""

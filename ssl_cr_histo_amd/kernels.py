@@ -36,11 +36,12 @@ last_conv_kernel = ""       # kernel instance the most recent conv2d() launched 
 
 def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bias=None, residual=None, relu=False,
            want_stats=False, out=None, transposed=False, out_hw=None, osh=1, accumulate=False, pixel_hw=None,
-           pix_mul=0, pix_off=(0, 0), tap_mask=0, mask=None, par4=False):
+           pix_mul=0, pix_off=(0, 0), tap_mask=0, mask=None, par4=False, seg_images=0):
     """x NHWC [N,H,W,C], w KRSC [K,R,S,C] -> y NHWC (+ partial stats [rows,2,K] fp32).
 
     transposed=True is the dgrad gather: pixel space = the conv's input (pixel_hw), x = dY, w = [C][R][S][K].
-    mask = (x_bn [like y], scale [K], shift [K], mean [K]): BatchNorm-backward front end, see sslcr_conv_desc.mask_x."""
+    mask = (x_bn [like y], scale [K], shift [K], mean [K]): BatchNorm-backward front end, see sslcr_conv_desc.mask_x.
+    seg_images > 0: N / seg_images segments in one launch (in_scale / in_shift [nseg, C]; stats rows split by segment)."""
     _chk(x, w, in_scale, in_shift, bias, residual, out)
     dt = _dt(x)
     N, H, W, C = x.shape
@@ -56,6 +57,11 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
                    N, H, W, C, K, R, S, stride, pad, PH, PW, OH, OW, osh, int(transposed), int(in_relu), int(relu),
                    int(accumulate), int(pix_mul), int(pix_off[0]), int(pix_off[1]), int(tap_mask))
     d.par4 = int(par4)
+    if seg_images:
+        d.seg_images = int(seg_images)
+        d.seg_stride = int(in_scale.stride(0)) if in_scale is not None and in_scale.dim() == 2 else 0
+        if not L.lib().sslcr_conv2d_segments_ok(dt, d):
+            raise L.SslcrError("conv2d: no segment form for this shape / dtype")
     if mask is not None:
         _chk(*mask)
         d.mask_x, d.mask_scale, d.mask_shift, d.mask_mean = (L.ptr(t) for t in mask)
@@ -227,26 +233,29 @@ def stem_wgrad_pool(x_nchw, dw, raw, scale, shift, mean, invstd, pool, *, x2=Non
 
 
 def bn_finalize(partials, count, gamma, beta, *, running_mean=None, running_var=None, nbt=None, momentum=0.1,
-                eps=1e-5, replay=1):
-    """partial rows [rows,2,C] -> (scale, shift, mean, invstd); running stats updated in place `replay` times."""
+                eps=1e-5, replay=1, nseg=1):
+    """partial rows [rows,2,C] -> (scale, shift, mean, invstd); running stats updated in place `replay` times.
+    nseg > 1: the rows are nseg equal segments, the outputs are [nseg, C] (count = elements per channel of one segment)."""
     _chk(partials, gamma, beta, running_mean, running_var, nbt)
     rows, _, Cn = partials.shape
     dev = partials.device
-    scale, shift, mean, invstd = (torch.empty(Cn, dtype=torch.float32, device=dev) for _ in range(4))
-    stage = torch.empty((32, 2, Cn), dtype=torch.float64, device=dev)
+    shape = (nseg, Cn) if nseg > 1 else (Cn,)
+    scale, shift, mean, invstd = (torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(4))
+    stage = torch.empty((max(nseg, 1), 32, 2, Cn), dtype=torch.float64, device=dev)
     d = L.BnFinalizeDesc(L.ptr(partials), rows, Cn, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift),
                          L.ptr(mean), L.ptr(invstd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), momentum, eps,
-                         replay, None, None, L.ptr(stage))
+                         replay, None, None, L.ptr(stage), nseg if nseg > 1 else 0, Cn if nseg > 1 else 0)
     L.check(L.lib().sslcr_bn_finalize(d, L.stream_ptr()))
     return scale, shift, mean, invstd
 
 
-def bn_act(x, scale, shift, *, res=None, rscale=None, rshift=None, relu=True):
+def bn_act(x, scale, shift, *, res=None, rscale=None, rshift=None, relu=True, nseg=1):
+    """nseg > 1: x is nseg equal segments along its first dimension, scale / shift (/ rscale / rshift) are [nseg, C]."""
     _chk(x, scale, shift, res, rscale, rshift)
     y = torch.empty_like(x)
     Cn = x.shape[-1]
     d = L.BnActDesc(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(res), L.ptr(rscale), L.ptr(rshift), L.ptr(y),
-                    x.numel() // Cn, Cn, int(relu))
+                    x.numel() // Cn, Cn, int(relu), nseg if nseg > 1 else 0, Cn if nseg > 1 else 0)
     L.check(L.lib().sslcr_bn_act(_dt(x), d, L.stream_ptr()))
     return y
 

@@ -440,6 +440,8 @@ def test_rsp_full_size_step_vs_reference(dtype):
     (i1, i2, i3, tgt), = C.rsp_batches(name)
     hw = c["hw"]
     eng.step_supervised(net_, "ce", [v.reshape(-1, 3, hw, hw) for v in (i1, i2, i3)], tgt.long().reshape(-1), train=True)
+    # bf16: the three branches ran as segments of one launch per layer (sslcr_conv_desc.seg_images); fp32: pass by pass
+    assert net_.segments_used == (dtype == "bf16")
     names = [str(n) for n in g[f"{name}/grad_names"]]
     mine = [k for k, _ in list(model.named_parameters()) + list(cls.named_parameters())]
     assert names == mine

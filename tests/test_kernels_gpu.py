@@ -848,3 +848,87 @@ def test_stem_conv_pool_rejects_unserved_shapes():
     wp32, bias32 = K.pack_stem(w.to(DEV), 0, bn=tuple(torch.ones(64, device=DEV) for _ in range(4)))
     with pytest.raises(L.SslcrError):
         K.stem_conv_pool(torch.zeros((2, 3, 64, 64), dtype=torch.uint8, device=DEV), wp32, bias32)
+
+
+# ---------------------------------------------------------------- segments: three TripletNet branches in one launch per layer
+SEG_CASES = [
+    # images per segment, H, W, C, K, R, stride, pad, prologue       (kernel the shape reaches)
+    (2, 32, 32, 64, 64, 3, 1, 1, False),      # conv3x3_pp64, few tiles per segment (grid < CUs)
+    (2, 32, 32, 64, 64, 3, 1, 1, True),
+    (24, 64, 64, 64, 64, 3, 1, 1, True),      # conv3x3_pp64, 85 workgroups per segment walk 384 tiles each
+    (3, 32, 32, 128, 128, 3, 1, 1, True),     # conv3x3_h16 ring form
+    (44, 32, 32, 128, 128, 3, 1, 1, False),   # conv3x3_h16, more items than workgroups
+    (2, 16, 16, 256, 256, 3, 1, 1, True),     # conv3x3_h16, two kout blocks
+    (8, 8, 8, 512, 512, 3, 1, 1, True),       # conv3x3_halo256 (four images per tile)
+    (4, 64, 64, 64, 128, 3, 2, 1, False),     # conv_dma 3x3 / 2
+    (8, 32, 32, 128, 256, 1, 2, 0, False),    # conv_dma 1x1 / 2
+]
+
+
+@pytest.mark.parametrize("case", SEG_CASES)
+def test_conv_segments_equal_separate_launches(case):
+    """sslcr_conv_desc.seg_images: one launch over three segments writes what three launches write (bit for bit), and the statistics
+    rows of segment s -- rows [s, s + 1) * rows / 3 -- add up to the rows of the separate launch."""
+    K = _k()
+    n, H, W, C, Ko, Rr, stride, pad, pro = case
+    dtype, nseg = 1, 3
+    x = to_dev(rnd(201, (nseg * n, H, W, C)), dtype)
+    w = to_dev(rnd(202, (Ko, Rr, Rr, C), 0.05), dtype)
+    sc = (rnd(203, (nseg, C)).abs() + 0.5).to(DEV) if pro else None
+    sh = rnd(204, (nseg, C), 0.3).to(DEV) if pro else None
+    y, st = K.conv2d(x, w, stride, pad, in_scale=sc, in_shift=sh, in_relu=pro, want_stats=True, seg_images=n)
+    name = K.last_conv_kernel
+    rows = st.shape[0]
+    assert rows % nseg == 0
+    for s in range(nseg):
+        ys, sts = K.conv2d(x[s * n:(s + 1) * n].contiguous(), w, stride, pad, in_scale=sc[s].contiguous() if pro else None,
+                           in_shift=sh[s].contiguous() if pro else None, in_relu=pro, want_stats=True)
+        assert K.last_conv_kernel == name
+        assert torch.equal(y[s * n:(s + 1) * n].view(torch.int16), ys.view(torch.int16)), (s, name)
+        got = st[s * rows // nseg:(s + 1) * rows // nseg].double().sum(0)
+        want = sts.double().sum(0)
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-3 * float(want.abs().max())), (s, name, float((got - want).abs().max()))
+
+
+def test_conv_segments_rejected_where_no_kernel_has_the_form():
+    K = _k()
+    from ssl_cr_histo_amd import _lib as L
+    x32 = torch.zeros((6, 32, 32, 64), dtype=torch.float32, device=DEV)
+    w32 = torch.zeros((64, 3, 3, 64), dtype=torch.float32, device=DEV)
+    with pytest.raises(L.SslcrError):
+        K.conv2d(x32, w32, 1, 1, want_stats=True, seg_images=2)                       # fp32: segments are a bf16 form
+    xb = torch.zeros((6, 9, 11, 64), dtype=torch.bfloat16, device=DEV)
+    wb = torch.zeros((64, 3, 3, 64), dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(L.SslcrError):
+        K.conv2d(xb, wb, 1, 1, want_stats=True, seg_images=2)                         # not 16x16-tileable: the 64-pixel-tile kernel
+    with pytest.raises(L.SslcrError):
+        K.conv2d(torch.zeros((7, 32, 32, 64), dtype=torch.bfloat16, device=DEV), wb, 1, 1, seg_images=2)      # 7 images, segments of 2
+
+
+def test_bn_finalize_and_bn_act_segments():
+    """three BatchNorm batches in one finalize: outputs per segment and the running statistics after the three updates in order,
+    against three calls; bn_act over three segments against three calls."""
+    K = _k()
+    nseg, rows, Cn, count = 3, 96, 128, 4096.0
+    part = torch.from_numpy(np.random.RandomState(211).standard_normal((nseg * rows, 2, Cn)).astype(np.float32)).to(DEV)
+    part[:, 1] = part[:, 1].abs() * 40 + 50      # sum of squares large enough for a positive variance
+    gamma, beta = (rnd(212, (Cn,)).abs() + 0.5).to(DEV), rnd(213, (Cn,)).to(DEV)
+    rm0, rv0 = rnd(214, (Cn,)).to(DEV), (rnd(215, (Cn,)).abs() + 0.5).to(DEV)
+    rm, rv, nbt = rm0.clone(), rv0.clone(), torch.zeros(1, dtype=torch.int64, device=DEV)
+    outs = K.bn_finalize(part, count * rows, gamma, beta, running_mean=rm, running_var=rv, nbt=nbt, nseg=nseg)
+    rm1, rv1, nbt1 = rm0.clone(), rv0.clone(), torch.zeros(1, dtype=torch.int64, device=DEV)
+    for s in range(nseg):
+        one = K.bn_finalize(part[s * rows:(s + 1) * rows].contiguous(), count * rows, gamma, beta, running_mean=rm1, running_var=rv1, nbt=nbt1)
+        for a, b in zip(outs, one):
+            assert torch.equal(a[s], b), s
+    assert torch.equal(rm, rm1) and torch.equal(rv, rv1) and int(nbt) == int(nbt1) == nseg
+    x = to_dev(rnd(216, (nseg * 4, 16, 16, Cn)), 1)
+    res = to_dev(rnd(217, (nseg * 4, 16, 16, Cn)), 1)
+    sc, sh = outs[0], outs[1]
+    rsc, rsh = (rnd(218, (nseg, Cn)).abs() + 0.5).to(DEV), rnd(219, (nseg, Cn)).to(DEV)
+    for kw in ({}, {"res": res}, {"res": res, "rscale": rsc, "rshift": rsh}):
+        y = K.bn_act(x, sc, sh, nseg=nseg, **kw)
+        for s in range(nseg):
+            kws = {k: (v[s * 4:(s + 1) * 4].contiguous() if k == "res" else v[s].contiguous()) for k, v in kw.items()}
+            ys = K.bn_act(x[s * 4:(s + 1) * 4].contiguous(), sc[s].contiguous(), sh[s].contiguous(), **kws)
+            assert torch.equal(y[s * 4:(s + 1) * 4].view(torch.int16), ys.view(torch.int16)), (s, list(kw))
