@@ -63,8 +63,9 @@ typedef struct sslcr_conv_desc {
   /* Segments (models/net.py:50-66, TripletNet: three branches through ONE backbone, BatchNorm statistics per branch): with
      seg_images > 0 the N images are N / seg_images independent batches in one launch -- segment s reads its prologue from
      in_scale + s * seg_stride / in_shift + s * seg_stride, and the stats rows of segment s are rows
-     [s * rows / nseg, (s + 1) * rows / nseg) of sslcr_conv2d_partial_rows (no workgroup's rows mix segments).  Forward form only
-     (no mask_x); sslcr_conv2d fails where the kernel serving the shape has no segment form (sslcr_conv2d_segments_ok). */
+     [s * rows / nseg, (s + 1) * rows / nseg) of sslcr_conv2d_partial_rows (no workgroup's rows mix segments).  With mask_x the
+     segment's BatchNorm is mask_scale / mask_shift / mask_mean + s * seg_stride.  bf16 only; sslcr_conv2d fails where the kernel
+     serving the shape has no segment form (sslcr_conv2d_segments_ok). */
   int seg_images, seg_stride;
 } sslcr_conv_desc;
 int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream);

@@ -123,8 +123,9 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   float* s_msh = s_bias + a.K;
   float* s_mmu = s_msh + a.K;
   for (int i = tid; i < a.K; i += NT) {
-    s_bias[i] = mk ? a.mask_scale[i] : (a.bias ? a.bias[i] : 0.f);
-    if (mk) { s_msh[i] = a.mask_shift[i]; s_mmu[i] = a.mask_mean[i]; }
+    const size_t mo = (size_t)seg * a.seg_stride + i;          // the mask's BatchNorm is the segment's own
+    s_bias[i] = mk ? a.mask_scale[mo] : (a.bias ? a.bias[i] : 0.f);
+    if (mk) { s_msh[i] = a.mask_shift[mo]; s_mmu[i] = a.mask_mean[mo]; }
   }
   const float relu_lo = a.in_relu ? 0.f : -__builtin_inff();
 

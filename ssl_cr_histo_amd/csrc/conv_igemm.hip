@@ -335,10 +335,11 @@ const char* conv_kernel_name(int dtype, const ConvArgs& a) {
 //   conv_dma: rows in pixel order, no prologue; a pixel block must not straddle a segment
 bool conv_segments_ok(int dtype, const ConvArgs& a) {
   if (a.seg_images <= 0) return true;
-  if (dtype != DT_BF16 || a.N % a.seg_images != 0 || a.mask_x || a.transposed || a.par4) return false;
+  if (dtype != DT_BF16 || a.N % a.seg_images != 0 || a.transposed || a.par4) return false;
   const int nseg = a.N / a.seg_images;
   if (nseg > 8) return false;
-  if (conv_h16_ok(dtype, a)) return true;
+  if (conv_h16_ok(dtype, a)) return true;          // (with mask_x: mask_scale / mask_shift / mask_mean + s * seg_stride)
+  if (a.mask_x) return false;
   const int q = conv_halo256_mode(dtype, a);
   if (q) return q == 16 || a.seg_images % 4 == 0;
   if (conv_halo_tw(dtype, a)) return false;

@@ -115,8 +115,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
   }
   if (tid < 64) {
     if (XF) { s_scale[tid] = a.in_scale[(size_t)seg * a.seg_stride + tid]; s_shift[tid] = a.in_shift[(size_t)seg * a.seg_stride + tid]; }
-    s_bias[tid] = mk ? a.mask_scale[tid] : (a.bias ? a.bias[tid] : 0.f);
-    if (mk) { s_msh[tid] = a.mask_shift[tid]; s_mmu[tid] = a.mask_mean[tid]; }
+    const size_t mo = (size_t)seg * a.seg_stride + tid;        // the mask's BatchNorm is the segment's own
+    s_bias[tid] = mk ? a.mask_scale[mo] : (a.bias ? a.bias[tid] : 0.f);
+    if (mk) { s_msh[tid] = a.mask_shift[mo]; s_mmu[tid] = a.mask_mean[mo]; }
   }
   for (int i = tid; i < 1024; i += 512) s_f[320 + i] = 0.f;
 

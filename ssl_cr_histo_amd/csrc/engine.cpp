@@ -689,10 +689,13 @@ int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f3
 // slower per image than the same kernels at N = 640 (r03: conv3x3_h16 48.7 us against 149 us for five times the images).
 // The stem (three separate input tensors) and its pool stay per pass.  false = some layer has no segment form here: the caller
 // runs the passes one by one.
+bool segments_on() {
+  static const bool on = [] { const char* e = getenv("SSLCR_SEGMENTS"); return !(e && e[0] == '0'); }();
+  return on;
+}
 bool segments_servable(sslcr_net* n, int N, int H, int W) {
   sslcr_ctx* c = n->ctx;
-  static const bool on = [] { const char* e = getenv("SSLCR_SEGMENTS"); return !(e && e[0] == '0'); }();
-  if (!on || !n->triplet || c->dtype != DT_BF16 || c->fp8 || (sharded(c) && c->bn_sync) || c->prof.on) return false;
+  if (!segments_on() || !n->triplet || c->dtype != DT_BF16 || c->fp8 || (sharded(c) && c->bn_sync) || c->prof.on) return false;
   const Dims d = make_dims(H, W);
   int xh = d.ph, xw = d.pw;
   for (int i = 0; i < 8; ++i) {
@@ -1143,6 +1146,17 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       q.N = N * npass; q.H = oh; q.W = ow; q.C = B.c2.cin; q.K = B.c2.cout; q.R = 3; q.S = 3; q.stride = 1; q.pad = 1; q.OH = oh; q.OW = ow;
       c2_batched = wgrad_halo_tw(q) != 0 && (wgrad_halo_tw(q) == 16 || N % 2 == 0);
     }
+    // ... and conv2's dgrad with the BatchNorm-backward front end takes them as segments where the 16x16-tile kernel serves it
+    ConvArgs seg_m;
+    bool seg_dg = false;
+    if (npass > 1 && segments_on() && !c->prof.on) {
+      seg_m = conv_args(B.c2, nullptr, B.c2.w_dg, nullptr, N * npass, oh, ow);
+      seg_m.C = B.c2.cout; seg_m.K = B.c2.cin; seg_m.transposed = 0; seg_m.PH = oh; seg_m.PW = ow; seg_m.OH = oh; seg_m.OW = ow;
+      const BnSaved& s1 = P[0].bn[B.b1.bidx];
+      seg_m.mask_x = P[0].blk[i].raw1; seg_m.mask_scale = s1.scale; seg_m.mask_shift = s1.shift; seg_m.mask_mean = s1.mean;
+      seg_m.seg_images = N; seg_m.seg_stride = (int)(P[1].bn[B.b1.bidx].scale - s1.scale);
+      seg_dg = conv_h16_ok(dt, seg_m) && conv_segments_ok(dt, seg_m) && conv_partials_rows(seg_m) % npass == 0;
+    }
     for (int p = 0; p < npass; ++p) {
       PassState& ps = P[p];
       char *dOut = buf(kOut, p, so), *G = buf(kG, p, so), *dRaw2 = buf(kRaw2, p, so), *dAct1 = buf(kAct1, p, so), *dRaw1 = buf(kRaw1, p, so),
@@ -1175,6 +1189,7 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
         if (B.has_ds) TRYI(tap(i, 4, dRawD, N, oh, ow, B.ds.cout));
       }
       if (!c2_batched) TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st, 0, 0, 0));
+      if (seg_dg) continue;                      // conv2's dgrad runs once over the passes, below
       float* b1_rows = nullptr;
       int b1_nrows = 0;
       {
@@ -1200,6 +1215,26 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], dAct1, ps.blk[i].raw1, nullptr, b1_rows ? 0 : 1, dRaw1, nullptr, opix, (double)opix, st,
                        nullptr, 0, b1_rows, b1_nrows));
       if (p == 0) TRYI(tap(i, 3, dRaw1, N, oh, ow, B.c1.cout));
+    }
+    if (seg_dg) {
+      // conv2's dgrad of the three branches as segments of one launch (their scratch tensors are contiguous): segment s masks
+      // with its own bn1 and leaves its own rows of bn1's backward sums
+      float* rows = nullptr;
+      int nrows = 0;
+      seg_m.x = buf(kRaw2, 0, so); seg_m.y = buf(kAct1, 0, so);
+      TRYI(ensure_partials(c, seg_m, &rows, &nrows));
+      seg_m.stats = rows;
+      TRY(prof_conv(c, dt, seg_m, st));
+      TRYI(tap(i, 2, buf(kAct1, 0, so), N, oh, ow, B.c2.cin));
+      n->tap_flags[i] = 1;
+      const int per = nrows / npass;
+      for (int p = 0; p < npass; ++p) {
+        PassState& ps = P[p];
+        TRYI(wg_wait(c, 1, st));
+        TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], buf(kAct1, p, so), ps.blk[i].raw1, nullptr, 0, buf(kRaw1, p, so), nullptr, opix, (double)opix, st,
+                         nullptr, 0, rows + (size_t)p * per * 2 * B.b1.C, per));
+        if (p == 0) TRYI(tap(i, 3, buf(kRaw1, 0, so), N, oh, ow, B.c1.cout));
+      }
     }
     // weight gradients: one launch over the npass * N images (x and dy contiguous across passes)
     if (c2_batched)

@@ -890,6 +890,43 @@ def test_conv_segments_equal_separate_launches(case):
         assert torch.allclose(got, want, rtol=1e-5, atol=1e-3 * float(want.abs().max())), (s, name, float((got - want).abs().max()))
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 64), (24, 64, 64, 64), (3, 32, 32, 128), (2, 16, 16, 256)])
+def test_conv_mask_front_end_segments_equal_separate_launches(case):
+    """the BatchNorm-backward front end (sslcr_conv_desc.mask_x) over three segments, each with its own BatchNorm: gradients
+    bit-equal to three launches, the rows of (sum g, sum g (x - mean)) per segment add up to theirs."""
+    K = _k()
+    n, H, W, Cn = case
+    nseg = 3
+    dy = to_dev(rnd(221, (nseg * n, H, W, Cn)), 1)
+    w = to_dev(rnd(222, (Cn, 3, 3, Cn), 0.05), 1)
+    xbn = to_dev(rnd(223, (nseg * n, H, W, Cn)), 1)
+    sc, sh, mu = (rnd(224, (nseg, Cn)).abs() + 0.5).to(DEV), rnd(225, (nseg, Cn), 0.3).to(DEV), rnd(226, (nseg, Cn), 0.2).to(DEV)
+    from ssl_cr_histo_amd import _lib as L
+
+    def run(x_, m_, seg):
+        # (K.conv2d takes seg_stride from in_scale; with a mask the stride is the mask arrays')
+        N_ = x_.shape[0]
+        y = torch.empty((N_, H, W, Cn), dtype=x_.dtype, device=x_.device)
+        d = L.ConvDesc(L.ptr(x_), L.ptr(w), L.ptr(y), None, None, None, None, None, N_, H, W, Cn, Cn, 3, 3, 1, 1, H, W, H, W, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+        d.mask_x, d.mask_scale, d.mask_shift, d.mask_mean = (L.ptr(t) for t in m_)
+        d.seg_images, d.seg_stride = (seg, Cn) if seg else (0, 0)
+        rows = L.lib().sslcr_conv2d_partial_rows(d)
+        st = torch.empty((rows, 2, Cn), dtype=torch.float32, device=x_.device)
+        d.stats = L.ptr(st)
+        L.check(L.lib().sslcr_conv2d(1, d, L.stream_ptr()))
+        return y, st
+
+    y, st = run(dy, (xbn, sc, sh, mu), n)
+    rows = st.shape[0]
+    assert rows % nseg == 0
+    for s in range(nseg):
+        sl = slice(s * n, (s + 1) * n)
+        ys, sts = run(dy[sl].contiguous(), (xbn[sl].contiguous(), sc[s].contiguous(), sh[s].contiguous(), mu[s].contiguous()), 0)
+        assert torch.equal(y[sl].view(torch.int16), ys.view(torch.int16)), s
+        got, want = st[s * rows // nseg:(s + 1) * rows // nseg].double().sum(0), sts.double().sum(0)
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-3 * float(want.abs().max())), (s, float((got - want).abs().max()))
+
+
 def test_conv_segments_rejected_where_no_kernel_has_the_form():
     K = _k()
     from ssl_cr_histo_amd import _lib as L
