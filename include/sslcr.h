@@ -164,7 +164,8 @@ typedef struct sslcr_bn_finalize_desc {
   /* segments (sslcr_conv_desc.seg_images): nseg > 1 finalizes nseg BatchNorm batches in one call -- segment s owns partial rows
      [s * rows / nseg, (s + 1) * rows / nseg) and writes scale / shift / mean / invstd at + s * seg_stride floats; the running
      statistics take the nseg updates one after the other, segment 0 first, like nseg successive forward calls (count = elements
-     per channel of ONE segment).  Not with sums_out / sums_in. */
+     per channel of ONE segment).  With sums_out (rows -> sums only) segment s writes sums_out + s * seg_stride doubles.  Not
+     with sums_in. */
   int nseg, seg_stride;
 } sslcr_bn_finalize_desc;
 int sslcr_bn_finalize(const sslcr_bn_finalize_desc* d, void* stream);
@@ -208,6 +209,11 @@ typedef struct sslcr_bn_bwd_desc {
                              residual block needs g anyway).  Not with pool_dy. */
   float* dgamma; float* dbeta;   /* optional: the apply pass also accumulates the affine gradients (what sslcr_bn_param_grads does: */
   float pg_scale;                /*   dgamma += pg_scale * sums[1] * invstd, dbeta += pg_scale * sums[0]) -- one launch less per BatchNorm */
+  /* segments (sslcr_conv_desc.seg_images): nseg > 1 runs nseg BatchNorm batches in one launch -- `pixels` is then the total and
+     each segment an equal share of it (tensors contiguous across segments); segment s uses scale / shift / mean / invstd
+     + s * seg_stride floats and sums + s * sums_stride doubles; count = elements per channel of ONE segment; dgamma / dbeta take
+     the segments' contributions one after the other, segment 0 first.  Not with pool_dy. */
+  int nseg, seg_stride, sums_stride;
 } sslcr_bn_bwd_desc;
 int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream);

@@ -74,9 +74,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stage, int splits,
     }
     if (!lead) continue;
     if (a.sums_out) {
-      a.sums_out[c] = s;
-      a.sums_out[a.C + c] = ss;
-      return;
+      double* o = a.sums_out + (size_t)z * a.seg_stride;
+      o[c] = s;
+      o[a.C + c] = ss;
+      continue;
     }
     const size_t so = (size_t)z * a.seg_stride;
     const double mean = s / a.count;
@@ -96,7 +97,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stage, int splits,
       }
     }
   }
-  if (lead && a.running_mean) {
+  if (lead && a.running_mean && !a.sums_out) {
     a.running_mean[c] = rm;
     a.running_var[c] = rv;
     if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += (int64_t)a.replay * nseg;
@@ -108,7 +109,7 @@ hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
   double* stage = a.stage;
   int splits = 0;
   const int nseg = a.nseg > 1 ? a.nseg : 1;
-  if (nseg > 1 && (a.sums_in || a.sums_out || a.rows % nseg != 0)) return hipErrorInvalidValue;
+  if (nseg > 1 && (a.sums_in || a.rows % nseg != 0)) return hipErrorInvalidValue;
   if (!a.sums_in) {
     const int rows = a.rows / nseg;             // per segment
     splits = rows / 32;                         // >= 4 dependent row loads per thread before it is worth another block row
@@ -540,20 +541,48 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, const flo
   }
 }
 
-// affine gradients from the finished sums, by workgroup 0 of the apply pass (same arithmetic as bn_param_grads_kernel)
+// affine gradients from the finished sums, by workgroup 0 of the apply pass (same arithmetic as bn_param_grads_kernel); with
+// segments the contributions are added one after the other, like the per-segment launches would
 __device__ __forceinline__ void bn_bwd_param_grads(const BnBwdArgs& a) {
-  if (blockIdx.x != 0 || !a.dgamma || !a.dbeta) return;
+  if (blockIdx.x != 0 || blockIdx.y != 0 || !a.dgamma || !a.dbeta) return;
+  const int nseg = a.nseg > 1 ? a.nseg : 1;
   for (int c = threadIdx.x; c < a.C; c += 256) {
-    a.dgamma[c] += (float)(a.sums[a.C + c] * (double)a.invstd[c] * (double)a.pg_scale);
-    a.dbeta[c] += (float)(a.sums[c] * (double)a.pg_scale);
+    float dg = a.dgamma[c], db = a.dbeta[c];
+    for (int z = 0; z < nseg; ++z) {
+      const double* sums = a.sums + (size_t)z * a.sums_stride;
+      dg += (float)(sums[a.C + c] * (double)a.invstd[(size_t)z * a.seg_stride + c] * (double)a.pg_scale);
+      db += (float)(sums[c] * (double)a.pg_scale);
+    }
+    a.dgamma[c] = dg;
+    a.dbeta[c] = db;
   }
+}
+// the descriptor of segment blockIdx.y (sslcr_bn_bwd_desc.nseg): its share of the tensors, its constants, its sums
+template <typename T>
+__device__ __forceinline__ BnBwdArgs bn_bwd_segment(const BnBwdArgs& a) {
+  BnBwdArgs b = a;
+  if (a.nseg > 1) {
+    const int z = blockIdx.y;
+    b.pixels = a.pixels / a.nseg;
+    const size_t off = (size_t)z * b.pixels * a.C * sizeof(T);
+    if (a.dy) b.dy = reinterpret_cast<const char*>(a.dy) + off;
+    if (a.x) b.x = reinterpret_cast<const char*>(a.x) + off;
+    if (a.yact) b.yact = reinterpret_cast<const char*>(a.yact) + off;
+    if (a.dx) b.dx = reinterpret_cast<char*>(a.dx) + off;
+    if (a.gout) b.gout = reinterpret_cast<char*>(a.gout) + off;
+    const size_t so = (size_t)z * a.seg_stride;
+    b.scale = a.scale + so; b.shift = a.shift + so; b.mean = a.mean + so; b.invstd = a.invstd + so;
+    b.sums = a.sums + (size_t)z * a.sums_stride;
+  }
+  return b;
 }
 
 // NB threads per workgroup.  The per-channel sums end in fp64 atomics on 2C addresses, and atomics on ONE address serialise:
 // with 1024 workgroups of 256 threads each address took 1024 of them, ~18 us at the end of every launch (0.36 ms per step by
 // ablation).  Same number of waves as 256 workgroups of 1024 threads: a quarter of the chain.
 template <typename T, int NB>
-__global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
+__global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const BnBwdArgs a0) {
+  const BnBwdArgs a = bn_bwd_segment<T>(a0);
   constexpr int EPC = Elem<T>::EPC;
   extern __shared__ __attribute__((aligned(16))) char bn_red_smem[];
   float (*sm)[2 * EPC + 1] = reinterpret_cast<float (*)[2 * EPC + 1]>(bn_red_smem);
@@ -589,7 +618,8 @@ __global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const BnBwdArgs a) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a0) {
+  const BnBwdArgs a = bn_bwd_segment<T>(a0);
   constexpr int EPC = Elem<T>::EPC;
   const int cols = a.C / EPC;
   const size_t total = a.pixels * cols;
@@ -608,7 +638,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a) {
     cC[e] = -sc * m0 - cB[e] * a.mean[c];
     rsc[e] = sc; rsh[e] = a.shift[c];
   }
-  bn_bwd_param_grads(a);
+  bn_bwd_param_grads(a0);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float g[EPC], xf[EPC], d[EPC];
     bn_bwd_g<T>(a, i, rsc, rsh, g, xf);
@@ -776,8 +806,11 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   const int epc = dtype == DT_BF16 ? 8 : 4;
   const int cols = a.C / epc;
   if (cols > 256 || (256 % cols) != 0) return hipErrorInvalidValue;
+  const int nseg = a.nseg > 1 ? a.nseg : 1;      // grid y; the kernels take their segment's share (bn_bwd_segment)
+  if (nseg > 1 && (a.pool_dy || a.pixels % nseg != 0)) return hipErrorInvalidValue;
+  const size_t pixels = a.pixels / nseg;
   const int rpp = 256 / cols;
-  size_t blocks = (a.pixels + rpp - 1) / rpp;
+  size_t blocks = (pixels + rpp - 1) / rpp;
   blocks = (blocks + 7) / 8;                              // >= 8 passes per block
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
@@ -789,7 +822,7 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   if (blocks >= 512) {                 // big tensors: a quarter of the workgroups, four times the threads each
     constexpr int NB = 1024;
     const int rpp4 = NB / cols;
-    size_t b4 = ((a.pixels + rpp4 - 1) / rpp4 + 7) / 8;
+    size_t b4 = ((pixels + rpp4 - 1) / rpp4 + 7) / 8;
     if (b4 > 256) b4 = 256;
     const size_t lds = (size_t)NB * (2 * epc + 1) * sizeof(float);
     static std::atomic<bool> attr_done{false};
@@ -798,15 +831,15 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_reduce_kernel<float, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       attr_done = true;
     }
-    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 1024>), dim3((int)b4), dim3(NB), lds, st, a);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3((int)b4), dim3(NB), lds, st, a);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 1024>), dim3((int)b4, nseg), dim3(NB), lds, st, a);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3((int)b4, nseg), dim3(NB), lds, st, a);
     return hipGetLastError();
   }
   const size_t lds = (size_t)256 * (2 * epc + 1) * sizeof(float);
   if (dtype == DT_BF16) {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 256>), dim3((int)blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 256>), dim3((int)blocks, nseg), dim3(256), lds, st, a);
   } else {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 256>), dim3((int)blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 256>), dim3((int)blocks, nseg), dim3(256), lds, st, a);
   }
   return hipGetLastError();
 }
@@ -816,6 +849,7 @@ hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a0, hipStream_t st) {
   if (a.g_in_reduce) {      // the reduce pass left the masked gradient in gout: plain dy from here on
     a.dy = a.gout; a.yact = nullptr; a.relu_from_x = 0; a.gout = nullptr; a.g_in_reduce = 0;
   }
+  if (a.pool_dy && a.nseg > 1) return hipErrorInvalidValue;
   if (a.pool_dy) {
     const int epc = dtype == DT_BF16 ? 8 : 4;
     const size_t items = (a.pixels / ((size_t)a.pH * a.pW)) * ((a.pH + 1) / 2) * ((a.pW + 1) / 2) * (a.C / epc);
@@ -823,10 +857,13 @@ hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a0, hipStream_t st) {
     else hipLaunchKernelGGL(bn_bwd_apply_pool_kernel<float>, dim3(ew_grid(items)), dim3(256), 0, st, a);
     return hipGetLastError();
   }
+  const int nseg = a.nseg > 1 ? a.nseg : 1;
+  if (a.pixels % nseg != 0) return hipErrorInvalidValue;
+  const size_t per = a.pixels / nseg;
   if (dtype == DT_BF16) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(a.pixels * (a.C / 8))), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(ew_grid(per * (a.C / 8)), nseg), dim3(256), 0, st, a);
   } else {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(a.pixels * (a.C / 4))), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_grid(per * (a.C / 4)), nseg), dim3(256), 0, st, a);
   }
   return hipGetLastError();
 }

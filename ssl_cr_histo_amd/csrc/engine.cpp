@@ -952,14 +952,26 @@ double* take_sums(sslcr_ctx* c) {
   return (double*)c->bn_ring.p + (size_t)(c->bn_ring_i++) * sslcr_ctx::kBnSlot;
 }
 
+// nseg consecutive slots (nullptr if the ring cannot serve them)
+double* take_sums_n(sslcr_ctx* c, int nseg) {
+  if (!c->bn_ring.p || c->bn_ring_i + nseg > sslcr_ctx::kBnRing) return nullptr;
+  double* p = (double*)c->bn_ring.p + (size_t)c->bn_ring_i * sslcr_ctx::kBnSlot;
+  c->bn_ring_i += nseg;
+  return p;
+}
+
 int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
                  void* dx, void* gout, size_t pixels, double count, hipStream_t st, double* sums, BnBwdArgs* out, const PoolSrc* pool = nullptr,
-                 int g_in_reduce = 0, const float* sum_rows = nullptr, int n_sum_rows = 0, bool sums_zeroed = false) {
+                 int g_in_reduce = 0, const float* sum_rows = nullptr, int n_sum_rows = 0, bool sums_zeroed = false, int nseg = 1,
+                 int seg_stride = 0) {
+  // nseg > 1 (sslcr_bn_bwd_desc.nseg): the tensors hold nseg passes one after the other, `pixels` is their total, sv is pass 0's
+  // (the others seg_stride floats apart), `sums` the first of nseg consecutive ring slots, sum_rows / n_sum_rows cover all passes
   sslcr_ctx* c = n->ctx;
   BnBwdArgs a;
   memset(&a, 0, sizeof(a));
   a.dy = dy; a.x = x; a.yact = yact; a.scale = sv.scale; a.shift = sv.shift; a.mean = sv.mean; a.invstd = sv.invstd;
   a.sums = sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
+  if (nseg > 1) { a.nseg = nseg; a.seg_stride = seg_stride; a.sums_stride = sslcr_ctx::kBnSlot; }
   a.g_in_reduce = (g_in_reduce && yact && gout) ? 1 : 0;
   const bool synced = sharded(c) && c->bn_sync;
   if (n->rg[bn.pg] || n->rg[bn.pb]) {
@@ -976,8 +988,10 @@ int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy,
     BnFinalizeArgs r;
     memset(&r, 0, sizeof(r));
     r.partials = sum_rows; r.rows = n_sum_rows; r.C = bn.C; r.stage = c->bn_stage; r.sums_out = sums;
+    if (nseg > 1) { r.nseg = nseg; r.seg_stride = sslcr_ctx::kBnSlot; }
     TRY(launch_bn_finalize(r, st));
   } else {
+    if (!sums_zeroed && nseg > 1) return fail("bn_bwd_begin: segments need pre-zeroed ring slots");
     if (!sums_zeroed) TRY(hipMemsetAsync(sums, 0, 2 * bn.C * sizeof(double), st));
     TRY(launch_bn_bwd_reduce(c->dtype, a, st));
   }
@@ -1015,9 +1029,16 @@ int bn_bwd_end(sslcr_ctx* c, const BnBwdArgs& a, hipStream_t st) {
 
 int bn_backward(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
                 void* dx, void* gout, size_t pixels, double count, hipStream_t st, const PoolSrc* pool = nullptr, int g_in_reduce = 0,
-                const float* sum_rows = nullptr, int n_sum_rows = 0) {
+                const float* sum_rows = nullptr, int n_sum_rows = 0, int nseg = 1, int seg_stride = 0) {
   sslcr_ctx* c = n->ctx;
   BnBwdArgs a;
+  if (nseg > 1) {                                // the passes as segments: nseg consecutive ring slots (the caller checked there are)
+    double* sums = take_sums_n(c, nseg);
+    if (!sums) return fail("bn_backward: no ring slots for the segments");
+    TRYI(bn_bwd_begin(n, bn, sv, dy, x, yact, relu_from_x, dx, gout, pixels, count, st, sums, &a, pool, g_in_reduce, sum_rows, n_sum_rows, true,
+                      nseg, seg_stride));
+    return bn_bwd_end(c, a, st);
+  }
   double* ring = sum_rows ? nullptr : take_sums(c);
   double* sums = ring ? ring : c->bn_sums;
   TRYI(bn_bwd_begin(n, bn, sv, dy, x, yact, relu_from_x, dx, gout, pixels, count, st, sums, &a, pool, g_in_reduce, sum_rows, n_sum_rows, ring != nullptr));
@@ -1157,6 +1178,35 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       seg_m.seg_images = N; seg_m.seg_stride = (int)(P[1].bn[B.b1.bidx].scale - s1.scale);
       seg_dg = conv_h16_ok(dt, seg_m) && conv_segments_ok(dt, seg_m) && conv_partials_rows(seg_m) % npass == 0;
     }
+    // the elementwise BatchNorm-backward passes of the branches as segments of one launch (sslcr_bn_bwd_desc.nseg): the passes'
+    // saved tensors and scratch tensors are contiguous, their saved statistics seg_stride floats apart, their sums in
+    // consecutive ring slots.  Not with synced BatchNorm (one all-reduce per pass) and not under the profiler.
+    const bool seg_bn = npass > 1 && segments_on() && !c->prof.on && !(sharded(c) && c->bn_sync) && c->bn_ring.p &&
+                        c->bn_ring_i + 2 * npass <= sslcr_ctx::kBnRing;
+    const int bn_stride = npass > 1 ? (int)(P[1].bn[0].scale - P[0].bn[0].scale) : 0;
+    if (seg_bn) {
+      char *dOut = buf(kOut, 0, so), *G = buf(kG, 0, so), *dRaw2 = buf(kRaw2, 0, so), *dRawD = buf(kRawD, 0, so);
+      TRYI(wg_wait(c, 0, st));
+      if (B.has_ds) TRYI(wg_wait(c, 2, st));
+      const size_t apix = opix * npass;
+      if (B.has_ds) {
+        BnBwdArgs a2, ad;
+        double* sums_2 = take_sums_n(c, npass);
+        if (!sums_2) return fail("backbone_backward: ring slots");
+        TRYI(bn_bwd_begin(n, B.b2, P[0].bn[B.b2.bidx], dOut, P[0].blk[i].raw2, P[0].blk[i].y, 0, dRaw2, G, apix, (double)opix, st, sums_2, &a2, nullptr, 1,
+                          nullptr, 0, true, npass, bn_stride));
+        TRYI(bn_bwd_begin(n, B.bd, P[0].bn[B.bd.bidx], G, P[0].blk[i].rawd, nullptr, 0, dRawD, nullptr, apix, (double)opix, st, sums_2 + 2 * B.b2.C, &ad,
+                          nullptr, 0, nullptr, 0, true, npass, bn_stride));
+        TRYI(bn_bwd_end(c, a2, st));
+        TRYI(bn_bwd_end(c, ad, st));
+      } else {
+        TRYI(bn_backward(n, B.b2, P[0].bn[B.b2.bidx], dOut, P[0].blk[i].raw2, P[0].blk[i].y, 0, dRaw2, G, apix, (double)opix, st, nullptr, 1, nullptr, 0,
+                         npass, bn_stride));
+      }
+      TRYI(tap(i, 0, G, N, oh, ow, B.c2.cout));
+      TRYI(tap(i, 1, dRaw2, N, oh, ow, B.c2.cout));
+      if (B.has_ds) TRYI(tap(i, 4, dRawD, N, oh, ow, B.ds.cout));
+    }
     for (int p = 0; p < npass; ++p) {
       PassState& ps = P[p];
       char *dOut = buf(kOut, p, so), *G = buf(kG, p, so), *dRaw2 = buf(kRaw2, p, so), *dAct1 = buf(kAct1, p, so), *dRaw1 = buf(kRaw1, p, so),
@@ -1164,6 +1214,7 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       // bn2 (+ relu mask from the block output): its REDUCE pass leaves G = dOut * (y > 0) in scratch; the apply pass, the
       // projection shortcut's BatchNorm and the identity path all read G instead of (dOut, y) again
       // (the previous block's side-stream weight gradients may still be reading dRaw2 / dRawD: order these writers behind them)
+      if (!seg_bn) {
       TRYI(wg_wait(c, 0, st));
       if (B.has_ds) TRYI(wg_wait(c, 2, st));
       // ... and with a projection shortcut the two reduce passes run back to back, so that sharded runs exchange both
@@ -1187,6 +1238,7 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
         TRYI(tap(i, 0, G, N, oh, ow, B.c2.cout));
         TRYI(tap(i, 1, dRaw2, N, oh, ow, B.c2.cout));
         if (B.has_ds) TRYI(tap(i, 4, dRawD, N, oh, ow, B.ds.cout));
+      }
       }
       if (!c2_batched) TRYI(wgrad_call(n, B.c2, ps.blk[i].raw1, dRaw2, &ps.bn[B.b1.bidx], N, oh, ow, oh, ow, st, 0, 0, 0));
       if (seg_dg) continue;                      // conv2's dgrad runs once over the passes, below
@@ -1228,7 +1280,13 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
       TRYI(tap(i, 2, buf(kAct1, 0, so), N, oh, ow, B.c2.cin));
       n->tap_flags[i] = 1;
       const int per = nrows / npass;
-      for (int p = 0; p < npass; ++p) {
+      if (seg_bn) {
+        TRYI(wg_wait(c, 1, st));
+        TRYI(bn_backward(n, B.b1, P[0].bn[B.b1.bidx], buf(kAct1, 0, so), P[0].blk[i].raw1, nullptr, 0, buf(kRaw1, 0, so), nullptr, opix * npass,
+                         (double)opix, st, nullptr, 0, rows, nrows, npass, bn_stride));
+        TRYI(tap(i, 3, buf(kRaw1, 0, so), N, oh, ow, B.c1.cout));
+      }
+      for (int p = 0; p < npass && !seg_bn; ++p) {
         PassState& ps = P[p];
         TRYI(wg_wait(c, 1, st));
         TRYI(bn_backward(n, B.b1, ps.bn[B.b1.bidx], buf(kAct1, p, so), ps.blk[i].raw1, nullptr, 0, buf(kRaw1, p, so), nullptr, opix, (double)opix, st,

@@ -299,19 +299,25 @@ def avgpool_bwd(dy, shape, dtype):
 
 
 def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, want_g=False, count=None, pool=None,
-           g_in_reduce=False):
-    """-> (dx, sums[2,C] fp64, g|None).  g_in_reduce: the reduce pass writes g and the apply pass reads it (needs yact, want_g)."""
-    _chk(x, scale, shift, mean, invstd, yact)
+           g_in_reduce=False, nseg=1, dgamma=None, dbeta=None):
+    """-> (dx, sums[2,C] fp64, g|None).  g_in_reduce: the reduce pass writes g and the apply pass reads it (needs yact, want_g).
+    nseg > 1: x is nseg equal segments along its first dimension with constants [nseg, C]; sums come back [nseg, 2, C];
+    dgamma / dbeta (fp32 [C], accumulated into) take every segment's contribution."""
+    _chk(x, scale, shift, mean, invstd, yact, dgamma, dbeta)
     if dy is not None:
         _chk(dy)
     Cn = x.shape[-1]
     pixels = x.numel() // Cn
-    sums = torch.zeros((2, Cn), dtype=torch.float64, device=x.device)
+    sums = torch.zeros((nseg, 2, Cn) if nseg > 1 else (2, Cn), dtype=torch.float64, device=x.device)
     dx = torch.empty_like(x)
     g = torch.empty_like(x) if want_g else None
     d = L.BnBwdDesc(L.ptr(dy), L.ptr(x), L.ptr(yact), L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(invstd), L.ptr(sums),
-                    L.ptr(dx), L.ptr(g), pixels, Cn, int(relu_from_x), float(count if count is not None else pixels),
+                    L.ptr(dx), L.ptr(g), pixels, Cn, int(relu_from_x), float(count if count is not None else pixels // nseg),
                     None, None, 0, 0, 0, 0, None, int(g_in_reduce))
+    if dgamma is not None:
+        d.dgamma, d.dbeta, d.pg_scale = L.ptr(dgamma), L.ptr(dbeta), 1.0
+    if nseg > 1:
+        d.nseg, d.seg_stride, d.sums_stride = nseg, Cn, 2 * Cn
     if pool is not None:          # pool = (pooled_dy [N,OH,OW,C], argmax u8[, pooled output y]): dy arrives through the stem max-pool
         pdy, pam = pool[0], pool[1]
         _chk(pdy, pam)

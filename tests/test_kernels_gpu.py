@@ -969,3 +969,32 @@ def test_bn_finalize_and_bn_act_segments():
             kws = {k: (v[s * 4:(s + 1) * 4].contiguous() if k == "res" else v[s].contiguous()) for k, v in kw.items()}
             ys = K.bn_act(x[s * 4:(s + 1) * 4].contiguous(), sc[s].contiguous(), sh[s].contiguous(), **kws)
             assert torch.equal(y[s * 4:(s + 1) * 4].view(torch.int16), ys.view(torch.int16)), (s, list(kw))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("mode", ["yact_g_in_reduce", "relu_from_x", "plain"])
+def test_bn_bwd_segments_equal_separate_launches(mode, dtype):
+    """sslcr_bn_bwd_desc.nseg: reduce + apply over three segments against three pairs of launches -- dx, the masked gradient g
+    (bit for bit), the sums per segment, dgamma / dbeta after the three contributions in order."""
+    K = _k()
+    nseg, n, H, W, Cn = 3, 4, 16, 16, 128
+    dy = to_dev(rnd(231, (nseg * n, H, W, Cn)), dtype)
+    x = to_dev(rnd(232, (nseg * n, H, W, Cn)), dtype)
+    ya = to_dev(rnd(233, (nseg * n, H, W, Cn)), dtype) if mode == "yact_g_in_reduce" else None
+    sc, sh = (rnd(234, (nseg, Cn)).abs() + 0.5).to(DEV), rnd(235, (nseg, Cn), 0.3).to(DEV)
+    mu, inv = rnd(236, (nseg, Cn), 0.2).to(DEV), (rnd(237, (nseg, Cn)).abs() + 0.5).to(DEV)
+    kw = dict(yact=ya, relu_from_x=mode == "relu_from_x", want_g=mode == "yact_g_in_reduce", g_in_reduce=mode == "yact_g_in_reduce")
+    dg, db = torch.full((Cn,), 0.25, device=DEV), torch.full((Cn,), -0.5, device=DEV)
+    dx, sums, g = K.bn_bwd(dy, x, sc, sh, mu, inv, nseg=nseg, dgamma=dg, dbeta=db, **kw)
+    dg1, db1 = torch.full((Cn,), 0.25, device=DEV), torch.full((Cn,), -0.5, device=DEV)
+    for s in range(nseg):
+        sl = slice(s * n, (s + 1) * n)
+        kws = dict(kw, yact=ya[sl].contiguous() if ya is not None else None)
+        dxs, sums_s, gs = K.bn_bwd(dy[sl].contiguous(), x[sl].contiguous(), sc[s].contiguous(), sh[s].contiguous(), mu[s].contiguous(),
+                                   inv[s].contiguous(), dgamma=dg1, dbeta=db1, **kws)
+        # (the sums end in fp64 atomics whose order is not fixed, so a coefficient may round differently: not a bit comparison)
+        assert torch.allclose(dx[sl].float(), dxs.float(), rtol=1e-2 if dtype == 1 else 1e-5, atol=1e-2 if dtype == 1 else 1e-5), s
+        if g is not None:
+            assert torch.equal(g[sl].view(torch.uint8), gs.view(torch.uint8)), s
+        assert torch.allclose(sums[s], sums_s, rtol=1e-9, atol=1e-9 * float(sums_s.abs().max())), s      # fp64 atomics: order only
+    assert torch.allclose(dg, dg1, rtol=1e-6, atol=1e-6) and torch.allclose(db, db1, rtol=1e-6, atol=1e-6)
