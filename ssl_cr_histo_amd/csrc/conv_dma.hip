@@ -52,7 +52,18 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int wp = wave % WP, wk = wave / WP;
-  const int m0 = blockIdx.x * BP, k0 = blockIdx.y * BKO;
+  // grid x = (pixel block, kout block) pairs; workgroups land on XCD (linear id % 8), each with its own L2.  The KB kout blocks of
+  // one pixel block read the same input rows, so they are made neighbours ON ONE XCD (ids w, w + 8, ...): KB - 1 of the KB reads hit
+  // that L2 instead of going out to the fabric (r03: layer4.0.conv1 fetched its 84 MB input four times).
+  const int KB = a.K / BKO, PB = (int)gridDim.x / KB;
+  int pb, kb_i;
+  if ((PB & 7) == 0) {
+    const int w = blockIdx.x, grp = w / (8 * KB), r = w - grp * 8 * KB;
+    pb = grp * 8 + (r & 7); kb_i = r >> 3;
+  } else {
+    kb_i = (int)blockIdx.x / PB; pb = (int)blockIdx.x - kb_i * PB;
+  }
+  const int m0 = pb * BP, k0 = kb_i * BKO;
   const int PHW = a.PH * a.PW;
   const int M = a.N * PHW;
   const int pmul = a.pix_mul ? a.pix_mul : 1;
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
       row16_sum4(s2[j], s2[j + 1], s2[j + 2], s2[j + 3]);
     }
     if (li == 0) {
-      float* sp = a.stats + ((size_t)(blockIdx.x * WP + wp) * 2) * a.K + kb;
+      float* sp = a.stats + ((size_t)(pb * WP + wp) * 2) * a.K + kb;
 #pragma unroll
       for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
     }
@@ -275,7 +286,7 @@ static hipError_t launch_d(const ConvArgs& a, hipStream_t st) {
     attr_done = true;
   }
   if (a.par4 && (!a.transposed || a.stride != 2 || a.pix_mul != 2 || a.R != 3 || a.S != 3 || a.pad != 1 || a.stats)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(kern, dim3(cdiv(M, BP), a.K / BKO, a.par4 ? 4 : 1), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(cdiv(M, BP) * (a.K / BKO), 1, a.par4 ? 4 : 1), dim3(256), lds, st, a);
   return hipGetLastError();
 }
 
