@@ -45,7 +45,18 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad_kernel(const WgradArgs a, i
 
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kh = tid >> 8;
   const int li = lane & 15, g = lane >> 4;
-  const int k0 = blockIdx.x * (64 * KH), c0 = blockIdx.y * 64;
+  // grid x = (kout block, cin block, pixel split) triples, the gx * gy workgroups of one pixel split neighbours on one XCD
+  // (wgrad_halo.hip): their re-reads of the same dY / X rows hit its L2
+  const int gx = a.K / (64 * KH), gy = a.C / 64, GT = gx * gy, nsplit = (int)gridDim.x / GT;
+  int bz, bt;
+  if ((nsplit & 7) == 0) {
+    const int w = blockIdx.x, grp = w / (8 * GT), r = w - grp * 8 * GT;
+    bz = grp * 8 + (r & 7); bt = r >> 3;
+  } else {
+    bz = (int)blockIdx.x / GT; bt = (int)blockIdx.x - bz * GT;
+  }
+  const int by = bt / gx, bx = bt - by * gx;
+  const int k0 = bx * (64 * KH), c0 = by * 64;
   const int OHW = a.OH * a.OW;
   const int M = a.N * OHW;
   const int row = (tid & 255) / CPR, chunk = (tid & 255) % CPR;
@@ -59,13 +70,13 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad_kernel(const WgradArgs a, i
     r_shift[e] = xform ? a.in_shift[c0 + chunk * EPC + e] : 0.f;
   }
 
-  const int step0 = blockIdx.z * steps_per_split;
+  const int step0 = bz * steps_per_split;
   const int total_steps = (M + PS - 1) / PS;
   int nsteps = total_steps - step0;
   if (nsteps > steps_per_split) nsteps = steps_per_split;
   if (nsteps <= 0) {                            // (the launcher sizes the splits so that none is empty; a slab must still be defined)
     if (partials) {
-      const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const size_t wg = ((size_t)bz * gy + by) * gx + bx;
       for (int e = 0; e < TAPS * 4; ++e) partials[(wg * (TAPS * 4) + e) * NT + tid] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     return;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad_kernel(const WgradArgs a, i
   // acc[tap][t4]: D[row = kout 64*kh+16*t4+4g+j][col = cin 16*wave+li]  ->  dW[k][tap][c]
   const int RS = a.R * a.S;
   if (partials) {                               // accumulator slab + fold launch instead of atomics from here, see wgrad_halo.hip
-    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const size_t wg = ((size_t)bz * gy + by) * gx + bx;
     f32x4_t* sp = partials + wg * (TAPS * 4) * NT + tid;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -246,7 +257,7 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
   const int gx = a.K / (64 * KH), gy = a.C / 64;
   f32x4_t* slabs = (Elem<T>::DT == DT_BF16 && splits > 1 && TAPS == a.R * a.S)
                        ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * TAPS * 4 * 256 * KH * sizeof(f32x4_t))) : nullptr;
-  hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(256 * KH), lds, st, a, sps, slabs);
+  hipLaunchKernelGGL(kern, dim3(gx * gy * splits), dim3(256 * KH), lds, st, a, sps, slabs);
   if (slabs) return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, TAPS, KH, st);
   return hipGetLastError();
 }

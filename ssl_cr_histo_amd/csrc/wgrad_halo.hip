@@ -58,7 +58,19 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = (tid >> 6) & 3, kh = tid >> 8;         // cin tile, kout half
   const int li = lane & 15, g = lane >> 4;
-  const int k0 = blockIdx.x * (64 * KH), c0 = blockIdx.y * 64;
+  // grid x = (kout block, cin block, pixel split) triples.  The gx * gy workgroups of ONE pixel split read the same dY / X tiles
+  // (each its own channel slice, but a dY row is re-read by every cin block and an X row by every kout block): they are made
+  // neighbours on one XCD (linear ids w, w + 8, ...; workgroups land on XCD id % 8) so that those re-reads hit its L2
+  const int gx = a.K / (64 * KH), gy = a.C / 64, GT = gx * gy, splits = (int)gridDim.x / GT;
+  int bz, bt;
+  if ((splits & 7) == 0) {
+    const int w = blockIdx.x, grp = w / (8 * GT), r = w - grp * 8 * GT;
+    bz = grp * 8 + (r & 7); bt = r >> 3;
+  } else {
+    bz = (int)blockIdx.x / GT; bt = (int)blockIdx.x - bz * GT;
+  }
+  const int by = bt / gx, bx = bt - by * gx;
+  const int k0 = bx * (64 * KH), c0 = by * 64;
   const int chunk = tid % CPR, prow = tid / CPR;          // halo staging role
   const int chunky = tid % (CPR * KH), prowy = tid / (CPR * KH);   // dY staging role: 16-byte chunk of the KH*64 kouts, pixel row
   const bool xform = a.in_scale != nullptr;
@@ -73,12 +85,12 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
     s_aff[sg * 128 + 64 + ch] = xform ? a.in_shift[(size_t)sg * a.seg_stride + c0 + ch] : 0.f;
   }
   const int tiles_w = a.W / TW, tiles_h = a.H / TH;
-  const int t_begin = blockIdx.z * tiles_per_split;
+  const int t_begin = bz * tiles_per_split;
   int t_end = t_begin + tiles_per_split;
   if (t_end > ntiles) t_end = ntiles;
   if (t_begin >= t_end) {                       // (the launcher sizes the splits so that none is empty; a slab must still be defined)
     if (partials) {
-      const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const size_t wg = ((size_t)bz * gy + by) * gx + bx;
       for (int e = 0; e < 36; ++e) partials[(wg * 36 + e) * NT + tid] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
     return;
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
     // adds the slabs into dW.  As fp32 atomics straight into dW (one resident round of workgroups = 75 MB of 4-byte atomics
     // per launch, whatever the layer) they were 20-26 % of the kernel: 248 -> 175 us without them on the layer2 shape,
     // 186 us with these stores.
-    const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const size_t wg = ((size_t)bz * gy + by) * gx + bx;
     f32x4_t* sp = partials + wg * 36 * NT + tid;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -428,7 +440,7 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   const int gx = a.K / (64 * KH), gy = a.C / 64;
   // accumulator slabs + a fold launch instead of atomics from the kernel, when there is more than one split to fold
   f32x4_t* slabs = (BF && splits > 1) ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * 36 * 256 * KH * sizeof(f32x4_t))) : nullptr;
-  hipLaunchKernelGGL(kern, dim3(gx, gy, splits), dim3(256 * KH), lds, st, a, tps, ntiles, slabs);
+  hipLaunchKernelGGL(kern, dim3(gx * gy * splits), dim3(256 * KH), lds, st, a, tps, ntiles, slabs);
   if (slabs) return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, 9, KH, st);
   return hipGetLastError();
 }
