@@ -74,7 +74,7 @@ __device__ unsigned long long g_h16_prof[16][8];
 //     the ring, the short 8-MFMA steps of this shape left the HBM round trip of the halo half exposed and paid 8 barriers
 //     per 144 MFMAs.
 template <typename T, int BKO, int WK, bool XF, bool WR>
-__global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items) {
+__global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items, const int kshift) {
   constexpr int NT = 256 * WK;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int CE = 8 * EPC;                 // channels per 128-byte slab
@@ -174,11 +174,19 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   const char* wg = reinterpret_cast<const char*>(a.w);
   const int nslabs = a.C / CE;
 
+  // Item order.  kout-block-major (item = kb * tiles + tile) keeps a workgroup on one kout block for a long run of items, but the
+  // KBn kout blocks of a tile -- which read the same halo -- are then half a kernel apart and every one fetches it again
+  // (layer3, K = 256: the input was read twice, r03 PMC).  Where the walk stride G is a multiple of KBn the items go kout-block-
+  // FASTEST instead (item = tile * KBn + kb): a workgroup still sees ONE kout block (item % KBn = first % KBn for all its items,
+  // so its statistics rows are published once), and a tile's KBn blocks sit next to each other in one XCD's run of the round.
+  // KBn = K / BKO.
+  // (kshift >= 0 from the launcher: power-of-two block counts only -- mask and shift, no division; -1 = kout-block-major)
+  const bool kfast = kshift >= 0;
   struct Geo { int origin, k0, tile, n0, h0, w0; unsigned long long out; };
   auto geom = [&](int item) {
     Geo q;
-    const int kbi = item / tiles_total;
-    q.tile = item - kbi * tiles_total;
+    const int kbi = kfast ? item & ((1 << kshift) - 1) : item / tiles_total;
+    q.tile = kfast ? item >> kshift : item - kbi * tiles_total;
     q.k0 = kbi * BKO;
     int t = q.tile;
     const int tw_i = t % tiles_w; t /= tiles_w;
@@ -519,7 +527,8 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   }
 #endif
   if (a.stats) {
-    const int kb_first = first / tiles_total, kb_last = item / tiles_total;      // item = the last one processed
+    const int kb_first = kfast ? first & ((1 << kshift) - 1) : first / tiles_total;
+    const int kb_last = kfast ? kb_first : item / tiles_total;      // item = the last one processed
     for (int kbi = 0; kbi < a.K / BKO; ++kbi) {
       if (kbi >= kb_first && kbi <= kb_last) continue;
       for (int i = tid; i < 8 * BKO; i += NT) {
@@ -581,7 +590,9 @@ static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
   const int tiles = (a.N / nseg) * (a.H / 16) * (a.W / 16);             // per segment, like n_items
   const int n_items = tiles * (a.K / BKO);
   const int grid = h16_grid(a, BKO);                                    // one 8-wave workgroup per CU
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WK), lds, st, a, tiles, n_items);
+  const int kbn = a.K / BKO, gseg = grid / nseg;
+  const int kshift = (kbn > 1 && (kbn & (kbn - 1)) == 0 && (gseg & (kbn - 1)) == 0) ? __builtin_ctz(kbn) : -1;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WK), lds, st, a, tiles, n_items, kshift);
   return hipGetLastError();
 }
 
