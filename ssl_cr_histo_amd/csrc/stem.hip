@@ -163,8 +163,12 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
   }
   __syncthreads();
   int cur = 0;
-  if ((int)blockIdx.x < ntiles) {
-    const int t0 = blockIdx.x;
+  // XCD-aware walk (workgroups land on XCD blockIdx % 8): each XCD takes a contiguous run of tiles per round, so that neighbouring
+  // tiles' shared halo columns -- and the 64-byte sectors that a 37-byte uint8 row segment only partly uses -- hit one L2
+  const int G = gridDim.x;
+  const int vb = (G & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
+  if (vb < ntiles) {
+    const int t0 = vb;
     const int n = t0 / (tiles_h * tiles_w), rem = t0 - n * tiles_h * tiles_w;
     int ns = n;
     const void* xseg = stem_seg(a, ns);
@@ -184,12 +188,12 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
 #pragma unroll
   for (int j = 0; j < 16; ++j) bias[j] = a.bias ? a.bias[STEM_CH(j >> 2, g, j & 3)] : 0.f;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  for (int tile = vb; tile < ntiles; tile += G) {
     const int n = tile / (tiles_h * tiles_w), rem = tile - n * tiles_h * tiles_w;
     const int th = rem / tiles_w, tw = rem - th * tiles_w;
     const int ho0 = th * TH, wo0 = tw * TW;
     const T* halo = halo0 + cur * (HR * HC * 4);
-    const int nxt = tile + gridDim.x;
+    const int nxt = tile + G;
     if (nxt < ntiles) {
       int nn = nxt / (tiles_h * tiles_w);
       const int nrem = nxt - nn * tiles_h * tiles_w;
@@ -815,7 +819,9 @@ __global__ __launch_bounds__(768) void stem_wgrad_pool2_kernel(const StemWgradAr
   };
   auto stage = [&](int k) -> char* { return smem + k * P2_STAGE; };
 
-  const int t0 = blockIdx.x, gs = gridDim.x;
+  // XCD-aware walk like stem_fwd_kernel: an XCD takes a contiguous run of tiles per round (shared image halos and pooling windows)
+  const int gs = gridDim.x;
+  const int t0 = (gs & 7) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * (gs >> 3) + (int)(blockIdx.x >> 3);
   __syncthreads();                    // halo zero fill
   if (matrix) {
     if (t0 < ntiles) dma(t0, stage(0));
