@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; S=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kst
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -o k -- python $R/bench.py --steps $S --warmup 3 --no-cpu-baseline --no-also --no-roofline --no-pmc "$@" > /tmp/kst.log 2>&1
-tail -1 /tmp/kst.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bench', d['value'], 'img/s', d['ms_per_step'], 'ms/step')"
+grep "^{" /tmp/kst.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(\"bench under rocprofv3:\", d[\"value\"], \"img/s\", d[\"ms_per_step\"], \"ms/step\")"
 python - "$(find /tmp/kst -name '*kernel_stats.csv' | head -1)" $S <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
