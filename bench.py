@@ -22,7 +22,13 @@ import subprocess
 import sys
 import time
 
-import torch
+_T0 = time.time()
+import torch  # noqa: E402
+
+# a fresh box pages the image in on first use (`import torch` then takes 1-2 minutes instead of 1.5 s) and the child processes of
+# this run -- CPU baseline, rocprofv3 passes -- meet their own cold libraries: their wall bounds are stretched by what was seen here
+_T_IMPORT = time.time() - _T0
+COLD_EXTRA_S = min(300.0, 3.0 * _T_IMPORT) if _T_IMPORT > 15.0 else 0.0
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -80,7 +86,7 @@ def build_nets(device, classes=1, triplet=False):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
-CPU_BASELINE_WALL_S = 100.0       # hard bound on the whole leg (the child process is killed at the deadline)
+CPU_BASELINE_WALL_S = 100.0 + COLD_EXTRA_S       # hard bound on the whole leg (the child process is killed at the deadline)
 
 
 def cpu_baseline_child(args):
@@ -413,12 +419,12 @@ def pmc_in_run(args):
         for i, counters in enumerate(PMC_PASSES):
             cmd = [exe, "--pmc"] + counters.split() + ["--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, f"pass{i}"), "-o", "pmc",
                                                         "--"] + child
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd="/tmp", timeout=150)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd="/tmp", timeout=150 + COLD_EXTRA_S)
             if r.returncode != 0:
                 return None, f"rocprofv3 pass {i} exited with {r.returncode}: {r.stdout[-300:]}"
         doc = pmc_step_reduce.reduce_dir(out, command="python bench.py " + " ".join(child[2:]))
     except subprocess.TimeoutExpired:
-        return None, "a rocprofv3 --pmc pass did not finish in 150 s"
+        return None, f"a rocprofv3 --pmc pass did not finish in {150 + COLD_EXTRA_S:.0f} s"
     finally:
         shutil.rmtree(out, ignore_errors=True)
     if not doc["kernels"]:
