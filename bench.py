@@ -593,14 +593,16 @@ def main():
                 if tr and pmc_measured:
                     out["hbm_traffic_gb_per_step"] = round(sum(tr) / 4 / 1e9, 2)      # the child runs 2 warm-up + 2 timed steps
 
+    if cpu_thread is not None:
+        # (joined BEFORE the side legs: with 16-32 host threads of the CPU baseline running, the short launch-heavy legs below
+        # jittered by up to 40 % -- frozen backbone 7.2 / 10.0 / 13.1 ms on one box -- while the GPU sat waiting for the host)
+        cpu_thread.join()
+        out["cpu_baseline"] = cpu_box.get("r")
     if rank == 0 and world == 1 and not args.no_also and args.workload == "ssl_cr" and args.dtype == "bf16":
         # the other BASELINE.json configurations on the same box (short runs: they are records, not the headline)
         del keep
         torch.cuda.empty_cache()
         out["also"] = also_records(args)
-    if cpu_thread is not None:
-        cpu_thread.join()
-        out["cpu_baseline"] = cpu_box.get("r")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
