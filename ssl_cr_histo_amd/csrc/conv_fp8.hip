@@ -384,11 +384,7 @@ static hipError_t launch_f8(const ConvArgs& a, const Fp8Args& q, hipStream_t st)
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, v = 0;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-  }
+  const int cus = device_cus();
   const int ntiles = TW == 16 ? a.N * (a.H / 16) * (a.W / 16) : a.N / 4;
   if ((size_t)a.N * a.H * a.W * a.C * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;      // 32-bit lane offsets (see load_chunk)
   const int gy = a.K / 128;

@@ -539,16 +539,6 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   }
 }
 
-static int device_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-      cus = 256;
-  }
-  return cus;
-}
-
 bool conv_h16_ok(int dtype, const ConvArgs& a) {
   if (a.in_scale && a.residual) return false;          // not a ResNet combination; the older halo kernels take it
   if (a.mask_x) {

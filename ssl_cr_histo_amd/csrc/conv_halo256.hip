@@ -356,11 +356,7 @@ static hipError_t launch_qt(const ConvArgs& a, int mode, hipStream_t st) {
     // one workgroup per CU and (tile, 128-kout block) item: when the last round would occupy at most half the CUs (N=640 at
     // layer4: 640 items = 2.5 rounds of 256), its tiles run as 64-kout half-items on all of them instead -- ~0.6 of a round
     // instead of a whole one
-    int cus = 256;
-    {
-      int dev = 0, v = 0;
-      if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-    }
+    const int cus = device_cus();
     const int tiles = conv_halo256_tiles(a, 8), kb = a.K / 128, items = tiles * kb, rem = items % cus;
     if (rem != 0 && 2 * rem <= cus && rem % kb == 0) {          // (also the whole launch when it has at most cus / 2 items: N=128)
       const int tail = rem / kb;

@@ -329,6 +329,15 @@ const char* conv_kernel_name(int dtype, const ConvArgs& a) {
   return bf ? "sslcr::conv_igemm_kernel<unsigned short, 64, 64>" : "sslcr::conv_igemm_kernel<float, 64, 64>";
 }
 
+int device_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  return cus;
+}
+
 // Segments (sslcr_conv_desc.seg_images): which kernels have the form, and where the row ranges come out right.
 //   conv3x3_h16 / conv3x3_pp64: the grid is split into nseg groups of workgroups (their statistics rows are per workgroup)
 //   conv3x3_halo256: one workgroup per tile, rows in tile order; a tile's images must not straddle a segment

@@ -433,18 +433,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
   }
 }
 
-static int pp_cus() {
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
-  return cus;
-}
 static int pp64_grid(const ConvArgs& a) {
   const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
   const int tiles = (a.N / nseg) * (a.H / 16) * (a.W / 16);       // per segment
-  const int pairs = (tiles + 1) / 2, per = pp_cus() / nseg;
+  const int pairs = (tiles + 1) / 2, per = device_cus() / nseg;
   return (pairs < per ? pairs : per) * nseg;
 }
 
@@ -462,7 +454,7 @@ bool conv_pp64_ok(int dtype, const ConvArgs& a) {
 int conv_pp64_rows(const ConvArgs& a) {
   if (a.seg_images > 0) return pp64_grid(a) * 4;
   const int tiles = a.N * (a.H / 16) * (a.W / 16);
-  return (tiles < pp_cus() ? tiles : pp_cus()) * 4;
+  return (tiles < device_cus() ? tiles : device_cus()) * 4;
 }
 
 hipError_t launch_conv_pp64(const ConvArgs& a, hipStream_t st) {

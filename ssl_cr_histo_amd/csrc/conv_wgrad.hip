@@ -235,11 +235,7 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
   const int tiles = (a.K / (64 * KH)) * (a.C / 64);
   // one resident round (160 KiB of LDS per CU = two narrow or one wide workgroup): the pixel split sets how many fp32
   // atomics hit dW, see wgrad_halo.hip
-  int cus = 256;
-  {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = device_cus();
   int splits = cdiv((TAPS == 1 ? 4 * cus : 2 * cus) / KH, tiles);     // 1x1: few atomics per workgroup, more parallel slices pay
   const int max_splits = cdiv(total_steps, 8);      // at least 8 steps per workgroup
   if (splits > max_splits) splits = max_splits;

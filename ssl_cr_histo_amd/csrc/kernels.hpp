@@ -29,6 +29,7 @@ const char* conv_kernel_name(int dtype, const ConvArgs& a);
 const char* wgrad_kernel_name(int dtype, const WgradArgs& a);
 int conv_partials_rows(const ConvArgs& a);
 bool conv_segments_ok(int dtype, const ConvArgs& a);
+int device_cus();      // compute units of the current device (asked once per process, thread-safely; 256 if the query fails)
 // conv_halo.hip
 int conv_halo_tw(int dtype, const ConvArgs& a);
 int conv_halo_tiles(const ConvArgs& a, int tw);

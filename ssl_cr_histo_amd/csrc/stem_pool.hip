@@ -263,11 +263,7 @@ hipError_t launch_stem_pool(int dtype, const StemArgs& a, int POH, int POW, hipS
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  int cus = 256;
-  {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = device_cus();
   const int grid = a.N < cus ? a.N : cus;
   if (a.in_f32) hipLaunchKernelGGL(stem_pool_fwd_kernel<true>, dim3(grid), dim3(SP_NT), lds, st, a, POH, POW);
   else hipLaunchKernelGGL(stem_pool_fwd_kernel<false>, dim3(grid), dim3(SP_NT), lds, st, a, POH, POW);

@@ -414,11 +414,7 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   const int kc = (a.K / (64 * KH)) * (a.C / 64);
   // exactly one resident round: two workgroups per CU.  The pixel split decides how many fp32 atomics hit dW
   // (workgroups x 64x64x9): with twice as many workgroups the final atomics alone were 22 % of the kernel.
-  int cus = 256;
-  {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-  }
+  const int cus = device_cus();
   int splits = cdiv((KH == 1 ? 2 : 1) * cus, kc);        // KH == 2: one 8-wave workgroup per CU
   const int max_splits = cdiv(ntiles, 16);                // at least 16 tiles per workgroup: below that the fp32 atomics of its 64x64x9 block outweigh the parallelism (RSP N=128: +4 % step)
   if (splits > max_splits) splits = max_splits;

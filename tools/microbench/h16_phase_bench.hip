@@ -8,6 +8,7 @@
 namespace sslcr {                                  // what conv_h16.hip takes from its neighbours
 int conv_halo256_mode(int, const ConvArgs&) { return 16; }
 bool conv_pp64_ok(int, const ConvArgs&) { return false; }
+int device_cus() { return 256; }
 hipError_t launch_conv_pp64(const ConvArgs&, hipStream_t) { return hipErrorInvalidValue; }
 const char* conv_pp64_name(const ConvArgs&) { return ""; }
 }

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+namespace sslcr { int device_cus() { return 256; } }
 using namespace sslcr;
 
 int main(int argc, char** argv) {
