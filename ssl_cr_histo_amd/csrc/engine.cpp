@@ -621,56 +621,71 @@ int alloc_passes(sslcr_net* n, int npass, int N, int H, int W) {
 }
 
 // ---------------------------------------------------------------- backbone forward, train mode (saves everything)
-int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f32, int N, int H, int W, int replay, hipStream_t st) {
+// stem of one pass: conv1 7x7/2 with statistics -> bn0 finalize -> BatchNorm + ReLU + max-pool into ps.pooled
+int forward_stem(sslcr_net* n, PassState& ps, const void* x, int in_f32, int N, int H, int W, int replay, hipStream_t st) {
   sslcr_ctx* c = n->ctx;
   const int dt = c->dtype;
-  if (n->pass[0].N != N || n->pass[0].H != H || n->pass[0].W != W || !n->pass[0].mem.p) TRYI(alloc_passes(n, n->triplet ? 3 : 1, N, H, W));
-  ps.x = x; ps.in_f32 = in_f32;
-  ps.x2 = n->split_x2; ps.n_split = n->split_x2 ? n->split_n : 0;
   const Dims d = make_dims(H, W);
-  {
-    StemArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = x; a.x2 = ps.x2; a.n_split = ps.n_split; a.w = n->stem.w_fwd; a.y = ps.raw0;
-    a.N = N; a.H = H; a.W = W; a.OH = d.oh0; a.OW = d.ow0; a.in_f32 = in_f32;
-    const int rows = stem_partials_rows(a);
-    TRYI(c->partials.ensure((size_t)rows * 2 * 64 * sizeof(float)));
-    a.stats = (float*)c->partials.p;
-    TRY(launch_stem(dt, a, st));
-    TRYI(finalize_bn(n, n->bn0, a.stats, rows, (double)N * d.oh0 * d.ow0, ps.bn[0], replay, st));
-    PoolFwdArgs p;
-    memset(&p, 0, sizeof(p));
-    p.x = ps.raw0; p.scale = ps.bn[0].scale; p.shift = ps.bn[0].shift; p.y = ps.pooled; p.argmax = ps.argmax;
-    p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
-    TRY(launch_bn_relu_maxpool(dt, p, st));
-  }
+  ps.x = x; ps.in_f32 = in_f32;
+  StemArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.x2 = ps.x2; a.n_split = ps.n_split; a.w = n->stem.w_fwd; a.y = ps.raw0;
+  a.N = N; a.H = H; a.W = W; a.OH = d.oh0; a.OW = d.ow0; a.in_f32 = in_f32;
+  const int rows = stem_partials_rows(a);
+  TRYI(c->partials.ensure((size_t)rows * 2 * 64 * sizeof(float)));
+  a.stats = (float*)c->partials.p;
+  TRY(launch_stem(dt, a, st));
+  TRYI(finalize_bn(n, n->bn0, a.stats, rows, (double)N * d.oh0 * d.ow0, ps.bn[0], replay, st));
+  PoolFwdArgs p;
+  memset(&p, 0, sizeof(p));
+  p.x = ps.raw0; p.scale = ps.bn[0].scale; p.shift = ps.bn[0].shift; p.y = ps.pooled; p.argmax = ps.argmax;
+  p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
+  TRY(launch_bn_relu_maxpool(dt, p, st));
+  return 0;
+}
+
+// the eight residual blocks + average pool from ps.pooled on.  nseg == 1: one pass of N images.  nseg > 1: ps is the FIRST of nseg
+// passes whose saved tensors follow one another (alloc_passes) -- every layer is then one launch over nseg * N images with
+// seg_images = N in its descriptor, one finalize and one bn_act for the nseg BatchNorm batches (see segments_servable)
+int forward_blocks(sslcr_net* n, PassState& ps, int N, int H, int W, int replay, int nseg, hipStream_t st) {
+  sslcr_ctx* c = n->ctx;
+  const int dt = c->dtype;
+  const Dims d = make_dims(H, W);
+  const bool segs = nseg > 1;
+  const int NT = nseg * N;
+  const int seg_stride = segs ? (int)(n->pass[1].bn[0].scale - n->pass[0].bn[0].scale) : 0;
   const char* X = ps.pooled;
   int xh = d.ph, xw = d.pw;
   for (int i = 0; i < 8; ++i) {
     BlockL& B = n->blocks[i];
     const int oh = d.lh[i], ow = d.lw[i];
+    const double cnt = (double)N * oh * ow;
     float* part; int rows;
-    ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fwd, ps.blk[i].raw1, N, xh, xw);
-    TRYI(ensure_partials(c, a1, &part, &rows, use_fp8(c, B.c1, a1)));
+    ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fwd, ps.blk[i].raw1, NT, xh, xw);
+    if (segs) a1.seg_images = N;
+    TRYI(ensure_partials(c, a1, &part, &rows, !segs && use_fp8(c, B.c1, a1)));
     a1.stats = part;
-    TRY(prof_conv_fwd(c, dt, a1, B.c1, false, st));
-    TRYI(finalize_bn(n, B.b1, part, rows, (double)N * oh * ow, ps.bn[B.b1.bidx], replay, st));
-    ConvArgs a2 = conv_args(B.c2, ps.blk[i].raw1, B.c2.w_fwd, ps.blk[i].raw2, N, oh, ow);
+    TRY(segs ? prof_conv(c, dt, a1, st) : prof_conv_fwd(c, dt, a1, B.c1, false, st));
+    TRYI(finalize_bn(n, B.b1, part, rows, cnt, ps.bn[B.b1.bidx], replay, st, nseg, seg_stride));
+    ConvArgs a2 = conv_args(B.c2, ps.blk[i].raw1, B.c2.w_fwd, ps.blk[i].raw2, NT, oh, ow);
     a2.in_scale = ps.bn[B.b1.bidx].scale; a2.in_shift = ps.bn[B.b1.bidx].shift; a2.in_relu = 1;
-    TRYI(ensure_partials(c, a2, &part, &rows, use_fp8(c, B.c2, a2)));
+    if (segs) { a2.seg_images = N; a2.seg_stride = seg_stride; }
+    TRYI(ensure_partials(c, a2, &part, &rows, !segs && use_fp8(c, B.c2, a2)));
     a2.stats = part;
-    TRY(prof_conv_fwd(c, dt, a2, B.c2, false, st));
-    TRYI(finalize_bn(n, B.b2, part, rows, (double)N * oh * ow, ps.bn[B.b2.bidx], replay, st));
+    TRY(segs ? prof_conv(c, dt, a2, st) : prof_conv_fwd(c, dt, a2, B.c2, false, st));
+    TRYI(finalize_bn(n, B.b2, part, rows, cnt, ps.bn[B.b2.bidx], replay, st, nseg, seg_stride));
     BnActArgs e;
     memset(&e, 0, sizeof(e));
     e.x = ps.blk[i].raw2; e.scale = ps.bn[B.b2.bidx].scale; e.shift = ps.bn[B.b2.bidx].shift;
-    e.y = ps.blk[i].y; e.pixels = (size_t)N * oh * ow; e.C = B.c2.cout; e.relu = 1;
+    e.y = ps.blk[i].y; e.pixels = (size_t)NT * oh * ow; e.C = B.c2.cout; e.relu = 1;
+    if (segs) { e.nseg = nseg; e.seg_stride = seg_stride; }
     if (B.has_ds) {
-      ConvArgs ad = conv_args(B.ds, X, B.ds.w_fwd, ps.blk[i].rawd, N, xh, xw);
+      ConvArgs ad = conv_args(B.ds, X, B.ds.w_fwd, ps.blk[i].rawd, NT, xh, xw);
+      if (segs) ad.seg_images = N;
       TRYI(ensure_partials(c, ad, &part, &rows));
       ad.stats = part;
-      TRY(prof_conv(c, dt,ad, st));
-      TRYI(finalize_bn(n, B.bd, part, rows, (double)N * oh * ow, ps.bn[B.bd.bidx], replay, st));
+      TRY(prof_conv(c, dt, ad, st));
+      TRYI(finalize_bn(n, B.bd, part, rows, cnt, ps.bn[B.bd.bidx], replay, st, nseg, seg_stride));
       e.res = ps.blk[i].rawd; e.rscale = ps.bn[B.bd.bidx].scale; e.rshift = ps.bn[B.bd.bidx].shift;
     } else {
       e.res = X;
@@ -678,8 +693,15 @@ int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f3
     TRY(launch_bn_act(dt, e, st));
     X = ps.blk[i].y; xh = oh; xw = ow;
   }
-  TRY(launch_avgpool_fwd(dt, X, ps.E, N, xh * xw, 512, st));
+  TRY(launch_avgpool_fwd(dt, X, ps.E, NT, xh * xw, 512, st));
   return 0;
+}
+
+int backbone_forward_train(sslcr_net* n, PassState& ps, const void* x, int in_f32, int N, int H, int W, int replay, hipStream_t st) {
+  if (n->pass[0].N != N || n->pass[0].H != H || n->pass[0].W != W || !n->pass[0].mem.p) TRYI(alloc_passes(n, n->triplet ? 3 : 1, N, H, W));
+  ps.x2 = n->split_x2; ps.n_split = n->split_x2 ? n->split_n : 0;
+  TRYI(forward_stem(n, ps, x, in_f32, N, H, W, replay, st));
+  return forward_blocks(n, ps, N, H, W, replay, 1, st);
 }
 
 // The TripletNet branches (models/net.py:50-66: three tiles through ONE backbone, BatchNorm statistics per call) as SEGMENTS of one
@@ -718,71 +740,13 @@ bool segments_servable(sslcr_net* n, int N, int H, int W) {
 }
 
 int backbone_forward_train_segments(sslcr_net* n, const void* const* xs, int in_f32, int N, int H, int W, hipStream_t st) {
-  sslcr_ctx* c = n->ctx;
-  const int dt = c->dtype;
   constexpr int NS = 3;
   if (n->pass[0].N != N || n->pass[0].H != H || n->pass[0].W != W || !n->pass[0].mem.p) TRYI(alloc_passes(n, NS, N, H, W));
-  const Dims d = make_dims(H, W);
-  const int seg_stride = (int)(((char*)n->pass[1].bn[0].scale - (char*)n->pass[0].bn[0].scale) / sizeof(float));
   for (int p = 0; p < NS; ++p) {
-    PassState& ps = n->pass[p];
-    ps.x = xs[p]; ps.in_f32 = in_f32; ps.x2 = nullptr; ps.n_split = 0;
-    StemArgs a;
-    memset(&a, 0, sizeof(a));
-    a.x = xs[p]; a.w = n->stem.w_fwd; a.y = ps.raw0;
-    a.N = N; a.H = H; a.W = W; a.OH = d.oh0; a.OW = d.ow0; a.in_f32 = in_f32;
-    const int rows = stem_partials_rows(a);
-    TRYI(c->partials.ensure((size_t)rows * 2 * 64 * sizeof(float)));
-    a.stats = (float*)c->partials.p;
-    TRY(launch_stem(dt, a, st));
-    TRYI(finalize_bn(n, n->bn0, a.stats, rows, (double)N * d.oh0 * d.ow0, ps.bn[0], 1, st));
-    PoolFwdArgs q;
-    memset(&q, 0, sizeof(q));
-    q.x = ps.raw0; q.scale = ps.bn[0].scale; q.shift = ps.bn[0].shift; q.y = ps.pooled; q.argmax = ps.argmax;
-    q.N = N; q.H = d.oh0; q.W = d.ow0; q.C = 64; q.OH = d.ph; q.OW = d.pw;
-    TRY(launch_bn_relu_maxpool(dt, q, st));
+    n->pass[p].x2 = nullptr; n->pass[p].n_split = 0;
+    TRYI(forward_stem(n, n->pass[p], xs[p], in_f32, N, H, W, 1, st));
   }
-  PassState& p0 = n->pass[0];                  // the first segment's tensors; the others follow contiguously
-  const char* X = p0.pooled;
-  int xh = d.ph, xw = d.pw;
-  for (int i = 0; i < 8; ++i) {
-    BlockL& B = n->blocks[i];
-    const int oh = d.lh[i], ow = d.lw[i];
-    float* part; int rows;
-    ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fwd, p0.blk[i].raw1, NS * N, xh, xw);
-    a1.seg_images = N;
-    TRYI(ensure_partials(c, a1, &part, &rows));
-    a1.stats = part;
-    TRY(prof_conv(c, dt, a1, st));
-    TRYI(finalize_bn(n, B.b1, part, rows, (double)N * oh * ow, p0.bn[B.b1.bidx], 1, st, NS, seg_stride));
-    ConvArgs a2 = conv_args(B.c2, p0.blk[i].raw1, B.c2.w_fwd, p0.blk[i].raw2, NS * N, oh, ow);
-    a2.in_scale = p0.bn[B.b1.bidx].scale; a2.in_shift = p0.bn[B.b1.bidx].shift; a2.in_relu = 1;
-    a2.seg_images = N; a2.seg_stride = seg_stride;
-    TRYI(ensure_partials(c, a2, &part, &rows));
-    a2.stats = part;
-    TRY(prof_conv(c, dt, a2, st));
-    TRYI(finalize_bn(n, B.b2, part, rows, (double)N * oh * ow, p0.bn[B.b2.bidx], 1, st, NS, seg_stride));
-    BnActArgs e;
-    memset(&e, 0, sizeof(e));
-    e.x = p0.blk[i].raw2; e.scale = p0.bn[B.b2.bidx].scale; e.shift = p0.bn[B.b2.bidx].shift;
-    e.y = p0.blk[i].y; e.pixels = (size_t)NS * N * oh * ow; e.C = B.c2.cout; e.relu = 1;
-    e.nseg = NS; e.seg_stride = seg_stride;
-    if (B.has_ds) {
-      ConvArgs ad = conv_args(B.ds, X, B.ds.w_fwd, p0.blk[i].rawd, NS * N, xh, xw);
-      ad.seg_images = N;
-      TRYI(ensure_partials(c, ad, &part, &rows));
-      ad.stats = part;
-      TRY(prof_conv(c, dt, ad, st));
-      TRYI(finalize_bn(n, B.bd, part, rows, (double)N * oh * ow, p0.bn[B.bd.bidx], 1, st, NS, seg_stride));
-      e.res = p0.blk[i].rawd; e.rscale = p0.bn[B.bd.bidx].scale; e.rshift = p0.bn[B.bd.bidx].shift;
-    } else {
-      e.res = X;
-    }
-    TRY(launch_bn_act(dt, e, st));
-    X = p0.blk[i].y; xh = oh; xw = ow;
-  }
-  TRY(launch_avgpool_fwd(dt, X, p0.E, NS * N, xh * xw, 512, st));
-  return 0;
+  return forward_blocks(n, n->pass[0], N, H, W, 1, NS, st);
 }
 
 // ---------------------------------------------------------------- backbone forward, eval mode (BN folded, nothing saved)
