@@ -750,33 +750,37 @@ int backbone_forward_train_segments(sslcr_net* n, const void* const* xs, int in_
 }
 
 // ---------------------------------------------------------------- backbone forward, eval mode (BN folded, nothing saved)
-int backbone_forward_eval(sslcr_net* n, const void* x, int in_f32, int N, int H, int W, float* E, hipStream_t st) {
+// npass > 1 (TripletNet under model.eval(): validate() of the RSP scripts): nothing in this mode depends on the batch, so the
+// branches' stems write into one buffer and every block conv runs once over npass * N images
+int backbone_forward_eval(sslcr_net* n, const void* const* xs, int npass, int in_f32, int N, int H, int W, float* const* E, hipStream_t st) {
   sslcr_ctx* c = n->ctx;
   const int dt = c->dtype;
   const size_t es = c->esz();
   const Dims d = make_dims(H, W);
+  const int NT = npass * N;
   Carver cv;
   const size_t o_a0 = cv.take((size_t)N * d.oh0 * d.ow0 * 64 * es);
-  const size_t unit = (size_t)N * d.ph * d.pw * 64 * es;
+  const size_t unit1 = (size_t)N * d.ph * d.pw * 64 * es, unit = unit1 * npass;
   size_t o_buf[4];
   for (int j = 0; j < 4; ++j) o_buf[j] = cv.take(unit);
   TRYI(c->scratch.ensure(cv.off));
   char* base = (char*)c->scratch.p;
-  {
+  for (int p = 0; p < npass; ++p) {
+    char* pooled = base + o_buf[0] + p * unit1;
     StemArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.w = n->stem.w_fold; a.y = base + o_a0; a.bias = n->stem.b_fold; a.relu = 1;
+    a.x = xs[p]; a.w = n->stem.w_fold; a.y = base + o_a0; a.bias = n->stem.b_fold; a.relu = 1;
     a.N = N; a.H = H; a.W = W; a.OH = d.oh0; a.OW = d.ow0; a.in_f32 = in_f32;
     if (stem_pool_ok(dt, a, d.ph, d.pw)) {
-      a.y = base + o_buf[0];                               // conv1 + folded BatchNorm + ReLU + max-pool in one launch: the conv output stays on the CU
+      a.y = pooled;                                        // conv1 + folded BatchNorm + ReLU + max-pool in one launch: the conv output stays on the CU
       TRY(launch_stem_pool(dt, a, d.ph, d.pw, st));
     } else {
       TRY(launch_stem(dt, a, st));
-      PoolFwdArgs p;
-      memset(&p, 0, sizeof(p));
-      p.x = base + o_a0; p.y = base + o_buf[0];            // plain max-pool: the stem's epilogue applied the folded BatchNorm + ReLU
-      p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
-      TRY(launch_bn_relu_maxpool(dt, p, st));
+      PoolFwdArgs q;
+      memset(&q, 0, sizeof(q));
+      q.x = base + o_a0; q.y = pooled;                     // plain max-pool: the stem's epilogue applied the folded BatchNorm + ReLU
+      q.N = N; q.H = d.oh0; q.W = d.ow0; q.C = 64; q.OH = d.ph; q.OW = d.pw;
+      TRY(launch_bn_relu_maxpool(dt, q, st));
     }
   }
   int xi = 0, xh = d.ph, xw = d.pw;
@@ -787,22 +791,23 @@ int backbone_forward_eval(sslcr_net* n, const void* x, int in_f32, int N, int H,
     char* td = base + o_buf[(xi + 2) & 3];
     char* Y = base + o_buf[(xi + 3) & 3];
     const int oh = d.lh[i], ow = d.lw[i];
-    ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fold, t1, N, xh, xw);
+    ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fold, t1, NT, xh, xw);
     a1.bias = B.c1.b_fold; a1.relu = 1;
     TRY(prof_conv_fwd(c, dt, a1, B.c1, true, st));
     const void* res = X;
     if (B.has_ds) {
-      ConvArgs ad = conv_args(B.ds, X, B.ds.w_fold, td, N, xh, xw);
+      ConvArgs ad = conv_args(B.ds, X, B.ds.w_fold, td, NT, xh, xw);
       ad.bias = B.ds.b_fold;
       TRY(prof_conv(c, dt,ad, st));
       res = td;
     }
-    ConvArgs a2 = conv_args(B.c2, t1, B.c2.w_fold, Y, N, oh, ow);
+    ConvArgs a2 = conv_args(B.c2, t1, B.c2.w_fold, Y, NT, oh, ow);
     a2.bias = B.c2.b_fold; a2.residual = res; a2.relu = 1;
     TRY(prof_conv_fwd(c, dt, a2, B.c2, true, st));
     xi = (xi + 3) & 3; xh = oh; xw = ow;
   }
-  TRY(launch_avgpool_fwd(dt, base + o_buf[xi], E, N, xh * xw, 512, st));
+  for (int p = 0; p < npass; ++p)
+    TRY(launch_avgpool_fwd(dt, base + o_buf[xi] + (size_t)p * N * xh * xw * 512 * es, E[p], N, xh * xw, 512, st));
   return 0;
 }
 
@@ -1373,9 +1378,9 @@ int net_forward(sslcr_net* n, int train, const void* const* xs, int in_f32, int 
     n->f8_calib_pass = true;
     TRYI(alloc_heads(n, N));
     int rc = 0;
-    for (int i = 0; i < npass_ && rc == 0; ++i)
-      rc = train ? backbone_forward_train(n, n->pass[i], xs[i], in_f32, N, H, W, n->triplet ? 1 : 3, st)
-                 : backbone_forward_eval(n, xs[i], in_f32, N, H, W, n->dE[i], st);
+    for (int i = 0; i < npass_ && rc == 0 && train; ++i)
+      rc = backbone_forward_train(n, n->pass[i], xs[i], in_f32, N, H, W, n->triplet ? 1 : 3, st);
+    if (!train) rc = backbone_forward_eval(n, xs, npass_, in_f32, N, H, W, n->dE, st);
     n->f8_calib_pass = false;
     if (rc) return rc;                           // not calibrated: the next forward tries again instead of running at scale 1
     n->f8_cal[train ? 0 : 1] = true;
@@ -1391,14 +1396,13 @@ int net_forward(sslcr_net* n, int train, const void* const* xs, int in_f32, int 
     TRYI(backbone_forward_train_segments(n, xs, in_f32, N, H, W, st));
     for (int i = 0; i < npass; ++i) E[i] = n->pass[i].E;
   }
-  for (int i = 0; i < npass && !segs; ++i) {
-    if (train) {
-      TRYI(backbone_forward_train(n, n->pass[i], xs[i], in_f32, N, H, W, n->triplet ? 1 : 3, st));
-      E[i] = n->pass[i].E;
-    } else {
-      E[i] = n->dE[i];         // borrow the dE buffers (unused in eval) for the embeddings
-      TRYI(backbone_forward_eval(n, xs[i], in_f32, N, H, W, E[i], st));
-    }
+  for (int i = 0; i < npass && !segs && train; ++i) {
+    TRYI(backbone_forward_train(n, n->pass[i], xs[i], in_f32, N, H, W, n->triplet ? 1 : 3, st));
+    E[i] = n->pass[i].E;
+  }
+  if (!train) {
+    for (int i = 0; i < npass; ++i) E[i] = n->dE[i];         // borrow the dE buffers (unused in eval) for the embeddings
+    TRYI(backbone_forward_eval(n, xs, npass, in_f32, N, H, W, E, st));
   }
   TRYI(heads_forward(n, E, npass, N, st));
   if (feats) TRY(hipMemcpyAsync(feats, n->feats, (size_t)N * 768 * 4, hipMemcpyDeviceToDevice, st));
