@@ -291,15 +291,25 @@ def make_workload(name, eng, args, device, rank, world, modules_student=None):
     return step, 3 * B, 3 * B * (F_FWD + F_BWD_FULL), cfg, (ms, cs, opt)
 
 
-def timed(step, warmup, steps, barrier):
+def timed(step, warmup, steps, barrier, per_step=None):
+    """W untimed steps, then exactly K steps between two barrier + synchronize points (host clock: the contract's number).
+    per_step (a list): also gets each step's duration in ms from HIP events recorded on the launch stream between the steps."""
     for _ in range(warmup):
         step()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
     barrier()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if ev:
+        ev[0].record()
+    for i in range(steps):
         step()
+        if ev:
+            ev[i + 1].record()
     barrier()
-    return time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if ev:
+        per_step.extend(ev[i].elapsed_time(ev[i + 1]) for i in range(steps))
+    return dt
 
 
 def also_child(args):
@@ -480,7 +490,8 @@ def main():
         torch.cuda.synchronize()
 
     step, patches, flops_step, cfg, keep = make_workload(args.workload, eng, args, device, rank, world)
-    dt = timed(step, args.warmup, args.steps, barrier)
+    per_step_ms = []
+    dt = timed(step, args.warmup, args.steps, barrier, per_step_ms)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -500,15 +511,16 @@ def main():
            "per_gpu_images_per_s": round(value / world, 1),
            "achieved_tflops_per_gpu_algorithmic": round(flops_step / (ms_per_step * 1e-3) / 1e12, 2),
            "ranks_seen": cworld, "collective_transport": transport}
-
-    cpu_thread, cpu_box = None, {}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "ssl_cr":
-        # the CPU baseline (host cores only, a child process with the GPU hidden) runs while this process does the roofline leg,
-        # the counter passes and the other configurations on the GPU: the two do not share a resource, and the default run
-        # stays within a few minutes
-        import threading
-        cpu_thread = threading.Thread(target=lambda: cpu_box.update(r=cpu_baseline(args)))
-        cpu_thread.start()
+    # each timed step by HIP events on the launch stream (this rank): median and spread beside the host-clock mean above
+    ps = sorted(per_step_ms)
+    out["ms_per_step_median_events"] = round(ps[len(ps) // 2] if len(ps) % 2 else 0.5 * (ps[len(ps) // 2 - 1] + ps[len(ps) // 2]), 3)
+    out["ms_per_step_min_max_events"] = [round(ps[0], 3), round(ps[-1], 3)]
+    from ssl_cr_histo_amd import _lib as _L
+    import hashlib
+    with open(_L.LIB_PATH, "rb") as f:
+        so_sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    out["library"] = {"path": os.path.relpath(_L.LIB_PATH, ROOT), "so_mtime": int(os.path.getmtime(_L.LIB_PATH)), "so_sha16": so_sha,
+                      "build_mode": "in-tree hipcc --offload-arch=gfx950 (ssl_cr_histo_amd/build.py), loaded through ctypes; no JIT, no fallback"}
 
     if rank == 0 and not args.no_roofline:
         # roofline leg: same steps again with every conv launch bracketed by HIP events on its own stream
@@ -593,11 +605,15 @@ def main():
                 if tr and pmc_measured:
                     out["hbm_traffic_gb_per_step"] = round(sum(tr) / 4 / 1e9, 2)      # the child runs 2 warm-up + 2 timed steps
 
-    if cpu_thread is not None:
-        # (joined BEFORE the side legs: with 16-32 host threads of the CPU baseline running, the short launch-heavy legs below
-        # jittered by up to 40 % -- frozen backbone 7.2 / 10.0 / 13.1 ms on one box -- while the GPU sat waiting for the host)
-        cpu_thread.join()
-        out["cpu_baseline"] = cpu_box.get("r")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "ssl_cr":
+        # the CPU baseline (host cores only, a child process with the GPU hidden) runs ALONE: after the roofline leg and the counter
+        # passes, before the side legs -- nothing else of this command is running, so the baseline of record is not taken on a
+        # host that is also driving the GPU from busy threads (round 3 overlapped them to save ~35 s of wall time)
+        load0 = os.getloadavg()[0]
+        out["cpu_baseline"] = cpu_baseline(args)
+        if out["cpu_baseline"]:
+            out["cpu_baseline"]["host"]["loadavg_1min_before"] = round(load0, 2)
+            out["cpu_baseline"]["host"]["concurrent_with_gpu_legs"] = False
     if rank == 0 and world == 1 and not args.no_also and args.workload == "ssl_cr" and args.dtype == "bf16":
         # the other BASELINE.json configurations on the same box (short runs: they are records, not the headline)
         del keep

@@ -194,7 +194,7 @@ int sslcr_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C
 typedef struct sslcr_bn_bwd_desc {
   const void* dy; const void* x; const void* yact;
   const float* scale; const float* shift; const float* mean; const float* invstd;
-  double* sums;           /* [2][C], zeroed by the caller before reduce */
+  double* sums;           /* [2][C]: OVERWRITTEN by the reduce pass (ordered sum of its workgroups' rows: same bits every run) */
   void* dx; void* gout;
   size_t pixels; int C; int relu_from_x; double count;
   const void* pool_dy;    /* optional: dy is not given directly but through maxpool3x3/2 pad 1 -- pooled gradient [N][pOH][pOW][C] ... */

@@ -140,8 +140,10 @@ def brightness_contrast_params(rng, brightness_limit=0.2, contrast_limit=0.2, p=
     rng.random()
     if not rng.random() < p:
         return False, 1.0, 0.0
-    alpha = 1.0 + rng.uniform(-abs(contrast_limit), abs(contrast_limit))
-    beta = 0.0 + rng.uniform(-abs(brightness_limit), abs(brightness_limit))
+    # to_tuple(limit) of 0.1.8 is (-limit, limit) UNSORTED and get_params draws random.uniform(limit[0], limit[1]) = a + (b - a) r:
+    # RandAugment's val = v / 30 * 0.4 - 0.2 is negative for v < 15, and the draw is then |val| (1 - 2 r), not |val| (2 r - 1)
+    alpha = 1.0 + rng.uniform(-contrast_limit, contrast_limit)
+    beta = 0.0 + rng.uniform(-brightness_limit, brightness_limit)
     return True, alpha, beta
 
 

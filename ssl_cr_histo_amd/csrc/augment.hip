@@ -109,7 +109,7 @@ hipError_t launch_hed_colour(const sslcr_colour_aug_desc& a, hipStream_t st) {
 // RandomBrightnessContrast -> functional.brightness_contrast_adjust under its @clipped decorator:
 //     out = clip(float32(img) * alpha + beta * mean(img), 0, max(img)).astype(uint8)
 // mean (float64) and max are over the WHOLE image (all three channels); the arithmetic is float32 with separate roundings of
-// the product and of the sum, the cast truncates.  Two launches: per-image (sum, max) by atomics into `stats`, then the map.
+// the product and of the sum, the cast truncates.  Two launches: per-image (sum, max) by INTEGER atomics into `stats` (order-independent), then the map.
 __global__ __launch_bounds__(256) void image_sum_max_kernel(const sslcr_brightness_contrast_desc a) {
   const size_t per = (size_t)3 * a.H * a.W;
   const int n = blockIdx.y;

@@ -577,11 +577,11 @@ __device__ __forceinline__ BnBwdArgs bn_bwd_segment(const BnBwdArgs& a) {
   return b;
 }
 
-// NB threads per workgroup.  The per-channel sums end in fp64 atomics on 2C addresses, and atomics on ONE address serialise:
-// with 1024 workgroups of 256 threads each address took 1024 of them, ~18 us at the end of every launch (0.36 ms per step by
-// ablation).  Same number of waves as 256 workgroups of 1024 threads: a quarter of the chain.
+// NB threads per workgroup.  A workgroup leaves its 2C per-channel sums as one fp64 row of `rows` ([segment][workgroup][2][C]);
+// bn_bwd_sums_kernel adds the rows in a fixed order.  (Until round 4 the sums ended in fp64 atomics on 2C addresses: an order that
+// changes run to run, and atomics on one address serialise -- ~18 us at the end of a 1024-workgroup launch.)
 template <typename T, int NB>
-__global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const BnBwdArgs a0) {
+__global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const BnBwdArgs a0, double* __restrict__ rows) {
   const BnBwdArgs a = bn_bwd_segment<T>(a0);
   constexpr int EPC = Elem<T>::EPC;
   extern __shared__ __attribute__((aligned(16))) char bn_red_smem[];
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(NB) void bn_bwd_reduce_kernel(const BnBwdArgs a0) {
     double acc = 0.0;
     for (int r = 0; r < rpp; ++r) acc += (double)sm[r * cols + cc][q];
     const int which = q / EPC, e = q - which * EPC;
-    atomicAdd(&a.sums[(size_t)which * a.C + cc * EPC + e], acc);
+    rows[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + which) * a.C + cc * EPC + e] = acc;
   }
 }
 
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a0) {
 // and for y == 0 the ReLU mask kills the gradient.  A channel with scale == 0 (gamma exactly 0) cannot be inverted: those
 // lanes fetch x at the argmax position instead.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs a) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs a, double* __restrict__ rows) {
   constexpr int EPC = Elem<T>::EPC;
   __shared__ float sm[256][2 * EPC + 1];
   const int cols = a.C / EPC;
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const BnBwdArgs
     double acc = 0.0;
     for (int r = 0; r < rpp; ++r) acc += (double)sm[r * cols + cc][q];
     const int which = q / EPC, e = q - which * EPC;
-    atomicAdd(&a.sums[(size_t)which * a.C + cc * EPC + e], acc);
+    rows[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 + which) * a.C + cc * EPC + e] = acc;
   }
 }
 
@@ -802,6 +802,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const BnBwdArgs 
   }
 }
 
+// sums[segment][2][C] = the workgroups' rows added in ONE fixed order: block = 64 consecutive values of a [2][C] row (x) by 16 row
+// lanes (y); row lane y adds rows y, y + 16, ... in rising order, lane 0 adds the 16 lane sums in lane order and writes.
+__global__ __launch_bounds__(1024) void bn_bwd_sums_kernel(const double* __restrict__ rows, int nrows, int C2, double* __restrict__ sums, int sums_stride) {
+  __shared__ double red[16][64];
+  const int v = blockIdx.x * 64 + threadIdx.x, yl = threadIdx.y;
+  const bool ok = v < C2;
+  const double* p = rows + ((size_t)blockIdx.y * nrows) * C2 + v;
+  double s = 0.0;
+  if (ok)
+    for (int r = yl; r < nrows; r += 16) s += p[(size_t)r * C2];
+  red[yl][threadIdx.x] = s;
+  __syncthreads();
+  if (yl != 0 || !ok) return;
+  for (int y = 1; y < 16; ++y) s += red[y][threadIdx.x];
+  sums[(size_t)blockIdx.y * sums_stride + v] = s;
+}
+
+// the reduce pass: per-workgroup rows, then their ordered sum OVERWRITES a.sums (no atomics: the same bits run after run)
 hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   const int epc = dtype == DT_BF16 ? 8 : 4;
   const int cols = a.C / epc;
@@ -814,16 +832,26 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
   blocks = (blocks + 7) / 8;                              // >= 8 passes per block
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  if (a.pool_dy && a.pool_y) {
-    if (dtype == DT_BF16) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<float>, dim3((int)blocks), dim3(256), 0, st, a);
-    return hipGetLastError();
-  }
-  if (blocks >= 512) {                 // big tensors: a quarter of the workgroups, four times the threads each
-    constexpr int NB = 1024;
-    const int rpp4 = NB / cols;
-    size_t b4 = ((pixels + rpp4 - 1) / rpp4 + 7) / 8;
+  const bool big = blocks >= 512 && !(a.pool_dy && a.pool_y);      // big tensors: a quarter of the workgroups, four times the threads each
+  size_t b4 = 0;
+  if (big) {
+    b4 = ((pixels + 1024 / cols - 1) / (1024 / cols) + 7) / 8;
     if (b4 > 256) b4 = 256;
+  }
+  const int nrows = (int)(big ? b4 : blocks);
+  double* rows = reinterpret_cast<double*>(wgrad_slabs(st, (size_t)nseg * nrows * 2 * a.C * sizeof(double)));
+  if (!rows) return hipErrorOutOfMemory;
+  auto fold = [&]() {
+    hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(2 * a.C, 64), nseg), dim3(64, 16), 0, st, rows, nrows, 2 * a.C, a.sums, nseg > 1 ? a.sums_stride : 0);
+    return hipGetLastError();
+  };
+  if (a.pool_dy && a.pool_y) {
+    if (dtype == DT_BF16) hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<bf16_t>, dim3((int)blocks), dim3(256), 0, st, a, rows);
+    else hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<float>, dim3((int)blocks), dim3(256), 0, st, a, rows);
+    return fold();
+  }
+  if (big) {
+    constexpr int NB = 1024;
     const size_t lds = (size_t)NB * (2 * epc + 1) * sizeof(float);
     static std::atomic<bool> attr_done{false};
     if (!attr_done) {
@@ -831,17 +859,17 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_reduce_kernel<float, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
       attr_done = true;
     }
-    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 1024>), dim3((int)b4, nseg), dim3(NB), lds, st, a);
-    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3((int)b4, nseg), dim3(NB), lds, st, a);
-    return hipGetLastError();
+    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 1024>), dim3((int)b4, nseg), dim3(NB), lds, st, a, rows);
+    else hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 1024>), dim3((int)b4, nseg), dim3(NB), lds, st, a, rows);
+    return fold();
   }
   const size_t lds = (size_t)256 * (2 * epc + 1) * sizeof(float);
   if (dtype == DT_BF16) {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 256>), dim3((int)blocks, nseg), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<bf16_t, 256>), dim3((int)blocks, nseg), dim3(256), lds, st, a, rows);
   } else {
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 256>), dim3((int)blocks, nseg), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 256>), dim3((int)blocks, nseg), dim3(256), lds, st, a, rows);
   }
-  return hipGetLastError();
+  return fold();
 }
 
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a0, hipStream_t st) {

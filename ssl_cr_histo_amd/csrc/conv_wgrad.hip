@@ -6,7 +6,7 @@
 // pixel-major ([pixel][64 channels], exactly as they sit in NHWC HBM) and the reduction dimension (pixels) is the
 // slow one, so bf16 fragments are fetched with the gfx950 transpose read ds_read_b64_tr_b16; fp32 uses scalar reads
 // into v_mfma_f32_16x16x4_f32.  One workgroup owns a 64(kout) x 64(cin) x all-taps tile for a slice of the pixels
-// and adds its fp32 result into dW with hardware float atomics (one slice per workgroup => few atomics per weight).
+// and leaves its fp32 result in a slab; the ordered fold of wgrad_halo.hip adds the slices into dW (no atomics: same bits every run).
 // The producer's BatchNorm+ReLU is applied to X on the load path, like in the forward conv.
 #include "kernels.hpp"
 
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad_kernel(const WgradArgs a, i
 
   // acc[tap][t4]: D[row = kout 64*kh+16*t4+4g+j][col = cin 16*wave+li]  ->  dW[k][tap][c]
   const int RS = a.R * a.S;
-  if (partials) {                               // accumulator slab + fold launch instead of atomics from here, see wgrad_halo.hip
+  if (partials) {                               // accumulator slab + ordered fold launch, see wgrad_halo.hip
     const size_t wg = ((size_t)bz * gy + by) * gx + bx;
     f32x4_t* sp = partials + wg * (TAPS * 4) * NT + tid;
 #pragma unroll
@@ -216,9 +216,9 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad_kernel(const WgradArgs a, i
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; ++j) {               // one pixel split: this workgroup is the only writer of its block of dW
         const int k = k0 + 64 * kh + 16 * t4 + 4 * g + j;
-        atomicAdd(a.dw + ((size_t)k * RS + t) * a.C + c0 + 16 * wave + li, acc[t][t4][j]);
+        a.dw[((size_t)k * RS + t) * a.C + c0 + 16 * wave + li] += acc[t][t4][j];
       }
 }
 
@@ -233,10 +233,10 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
   const int M = a.N * a.OH * a.OW;
   const int total_steps = cdiv(M, PS);
   const int tiles = (a.K / (64 * KH)) * (a.C / 64);
-  // one resident round (160 KiB of LDS per CU = two narrow or one wide workgroup): the pixel split sets how many fp32
-  // atomics hit dW, see wgrad_halo.hip
+  // one resident round (160 KiB of LDS per CU = two narrow or one wide workgroup): the pixel split sets how many slabs
+  // are written and folded, see wgrad_halo.hip
   const int cus = device_cus();
-  int splits = cdiv((TAPS == 1 ? 4 * cus : 2 * cus) / KH, tiles);     // 1x1: few atomics per workgroup, more parallel slices pay
+  int splits = cdiv((TAPS == 1 ? 4 * cus : 2 * cus) / KH, tiles);     // 1x1: a small slab per workgroup, more parallel slices pay
   const int max_splits = cdiv(total_steps, 8);      // at least 8 steps per workgroup
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -251,8 +251,12 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int gx = a.K / (64 * KH), gy = a.C / 64;
-  f32x4_t* slabs = (Elem<T>::DT == DT_BF16 && splits > 1 && TAPS == a.R * a.S)
-                       ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * TAPS * 4 * 256 * KH * sizeof(f32x4_t))) : nullptr;
+  if (TAPS != a.R * a.S) return hipErrorInvalidValue;
+  f32x4_t* slabs = nullptr;                      // accumulator slabs + the ordered fold whenever there is more than one pixel split
+  if (splits > 1) {
+    slabs = reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * TAPS * 4 * 256 * KH * sizeof(f32x4_t)));
+    if (!slabs) return hipErrorOutOfMemory;
+  }
   hipLaunchKernelGGL(kern, dim3(gx * gy * splits), dim3(256 * KH), lds, st, a, sps, slabs);
   if (slabs) return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, TAPS, KH, st);
   return hipGetLastError();

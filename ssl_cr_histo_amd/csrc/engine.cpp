@@ -181,8 +181,8 @@ struct sslcr_ctx {
   DevBuf small;       // bn stage/sums, unit scale/shift
   double* bn_stage = nullptr;
   double* bn_sums = nullptr;
-  // BatchNorm-backward sums: every reduce pass of one backward takes its own pre-zeroed [2][2][512]-double slot of this ring, and ONE
-  // memset per backward clears them all (a memset per BatchNorm was 13 launches of ~4.7 us per SSL_CR step, 46 per RSP step)
+  // BatchNorm-backward sums: every reduce pass of one backward takes its own [2][2][512]-double slot of this ring (the pass
+  // overwrites it with the ordered sum of its workgroups' rows: nothing to clear)
   DevBuf bn_ring;
   int bn_ring_i = 0;
   static constexpr int kBnRing = 96, kBnSlot = 2 * 2 * 512;
@@ -915,7 +915,7 @@ struct PoolSrc {            // gradient arriving through the stem max-pool (see 
 
 // BatchNorm backward in three parts so that independent BatchNorms (a block's bn2 and its projection-shortcut BatchNorm) can
 // share ONE all-reduce of their sums: begin = the reduce pass into `sums` ([2][C] doubles), sync = the all-reduce, end = the apply pass
-// the next pre-zeroed sums slot of this backward (nullptr when the ring is used up: the caller's buffer is then zeroed by a memset)
+// the next sums slot of this backward (nullptr when the ring is used up: the caller then uses c->bn_sums)
 double* take_sums(sslcr_ctx* c) {
   if (!c->bn_ring.p || c->bn_ring_i >= sslcr_ctx::kBnRing) return nullptr;
   return (double*)c->bn_ring.p + (size_t)(c->bn_ring_i++) * sslcr_ctx::kBnSlot;
@@ -960,8 +960,7 @@ int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy,
     if (nseg > 1) { r.nseg = nseg; r.seg_stride = sslcr_ctx::kBnSlot; }
     TRY(launch_bn_finalize(r, st));
   } else {
-    if (!sums_zeroed && nseg > 1) return fail("bn_bwd_begin: segments need pre-zeroed ring slots");
-    if (!sums_zeroed) TRY(hipMemsetAsync(sums, 0, 2 * bn.C * sizeof(double), st));
+    (void)sums_zeroed;                              // (the reduce pass overwrites its sums)
     TRY(launch_bn_bwd_reduce(c->dtype, a, st));
   }
   *out = a;
@@ -1420,7 +1419,6 @@ int net_backward(sslcr_net* n, const float* dlogits, hipStream_t st) {
   const bool bb = lowest_trainable(n) < 60;
   if (bb) {
     TRYI(c->bn_ring.ensure((size_t)sslcr_ctx::kBnRing * sslcr_ctx::kBnSlot * sizeof(double)));
-    TRY(hipMemsetAsync(c->bn_ring.p, 0, (size_t)sslcr_ctx::kBnRing * sslcr_ctx::kBnSlot * sizeof(double), st));
     c->bn_ring_i = 0;
   }
   TRYI(heads_backward(n, dlogits, npass, N, bb, st));

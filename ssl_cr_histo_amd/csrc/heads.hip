@@ -93,30 +93,35 @@ hipError_t launch_linear_fwd(const float* x, const float* w, const float* b, flo
   return gemm(x, K, 1, w, 1, K, y, M, N, K, b, relu, 0, st);
 }
 
-__global__ __launch_bounds__(256) void relu_mask_colsum_kernel(const float* dy, const float* yact, float* dym, float* db, int M, int N) {
-  // block = 64 columns x 4 row lanes over a 64-row slab: masks dy by (yact>0) into dym, column sums -> atomics into db
-  __shared__ float sm[4][64];
-  const int n = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  const int m0 = blockIdx.y * 64, m1 = min(M, m0 + 64);
+__global__ __launch_bounds__(1024) void relu_mask_colsum_kernel(const float* dy, const float* yact, float* dym, float* db, int M, int N) {
+  // block = 16 columns x 64 row lanes over ALL rows: masks dy by (yact > 0) into dym; the column sums are added in a fixed order
+  // (row lane by row lane, then the 64 lane sums in lane order) into db by their single owner -- the same bits run after run
+  __shared__ float sm[64][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + cl;
   float s = 0.f;
   if (n < N) {
-    for (int m = m0 + rl; m < m1; m += 4) {
+    for (int m = rl; m < M; m += 64) {
       float v = dy[(long)m * N + n];
       if (yact && !(yact[(long)m * N + n] > 0.f)) v = 0.f;
       if (dym) dym[(long)m * N + n] = v;
       s += v;
     }
   }
-  sm[rl][threadIdx.x & 63] = s;
+  sm[rl][cl] = s;
   __syncthreads();
-  if (db && rl == 0 && n < N) atomicAdd(db + n, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+  if (db && rl == 0 && n < N) {
+    float t = sm[0][cl];
+    for (int r = 1; r < 64; ++r) t += sm[r][cl];
+    db[n] += t;
+  }
 }
 
 hipError_t launch_linear_bwd(const float* x, const float* w, const float* dy, const float* yact, float* dx, float* dw, float* db,
                              int M, int N, int K, int dx_accumulate, float* scratch, hipStream_t st) {
   const float* g = dy;
   if (yact || db) {
-    hipLaunchKernelGGL(relu_mask_colsum_kernel, dim3(cdiv(N, 64), cdiv(M, 64)), dim3(256), 0, st, dy, yact, yact ? scratch : nullptr, db, M, N);
+    hipLaunchKernelGGL(relu_mask_colsum_kernel, dim3(cdiv(N, 16)), dim3(1024), 0, st, dy, yact, yact ? scratch : nullptr, db, M, N);
     if (yact) g = scratch;
   }
   hipError_t e = hipSuccess;

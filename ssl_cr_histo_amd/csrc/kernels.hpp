@@ -66,6 +66,7 @@ int wgrad_halo_tw(const WgradArgs& a);
 // accumulator slabs of the weight-gradient kernels (one buffer per stream) and the launch that folds them into dW, wgrad_halo.hip
 void* wgrad_slabs(hipStream_t st, size_t bytes);
 hipError_t launch_wgrad_fold(const void* slabs, float* dw, int C, int gx, int gy, int splits, int taps, int kh_n, hipStream_t st);
+hipError_t launch_stem_wgrad_fold(const void* slabs, float* dw, int nwg, hipStream_t st);
 hipError_t launch_wgrad_halo(int dtype, const WgradArgs& a, int tw, hipStream_t st);
 hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, hipStream_t st);
 // stem.hip

@@ -579,9 +579,9 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradArgs a, 
     const int r = f >> 1, s = (f & 1) * 4 + (li >> 2), c = li & 3;
     if (s < 7 && c < 3) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; ++j) {             // a one-workgroup launch: the only writer
         const int k = 16 * wave + 4 * g + j;
-        atomicAdd(a.dw + ((k * 3 + c) * 7 + r) * 7 + s, acc[f][j]);
+        a.dw[((k * 3 + c) * 7 + r) * 7 + s] += acc[f][j];
       }
     }
   }
@@ -923,28 +923,11 @@ __global__ __launch_bounds__(768) void stem_wgrad_pool2_kernel(const StemWgradAr
     const int r = f >> 1, s = (f & 1) * 4 + (li >> 2), c = li & 3;
     if (s < 7 && c < 3) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; ++j) {             // a one-workgroup launch: the only writer
         const int k = 16 * wave + 4 * g + j;
-        atomicAdd(a.dw + ((k * 3 + c) * 7 + r) * 7 + s, acc[f][j]);
+        a.dw[((k * 3 + c) * 7 + r) * 7 + s] += acc[f][j];
       }
     }
-  }
-}
-
-// dW += sum of the workgroups' slabs: block (x = accumulator vector f, y = chunk of 16 workgroups), thread = the kernel's thread
-__global__ __launch_bounds__(256) void stem_wgrad_fold_kernel(const f32x4_t* __restrict__ partials, float* dw, int nwg) {
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const int z0 = blockIdx.y * 16, z1 = min(nwg, z0 + 16);
-  f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
-  for (int z = z0; z < z1; ++z) {
-    const f32x4_t q = partials[((size_t)z * 14 + f) * 256 + tid];
-    sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2]; sum[3] += q[3];
-  }
-  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4;
-  const int r = f >> 1, s = (f & 1) * 4 + (li >> 2), c = li & 3;
-  if (s < 7 && c < 3) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) atomicAdd(dw + (((16 * wave + 4 * g + j) * 3 + c) * 7 + r) * 7 + s, sum[j]);
   }
 }
 
@@ -961,9 +944,14 @@ static hipError_t launch_stem_wgrad_t(const StemWgradArgs& a, const BnBwdArgs& b
     attr_done = true;
   }
   int grid = ntiles < 768 ? ntiles : 768;
-  f32x4_t* slabs = (Elem<T>::DT == DT_BF16 && grid > 16) ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t))) : nullptr;
+  // every workgroup holds a partial of the SAME 64 x 147 weights: slabs + the ordered fold (wgrad_halo.hip), in every dtype
+  f32x4_t* slabs = nullptr;
+  if (grid > 1) {
+    slabs = reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t)));
+    if (!slabs) return hipErrorOutOfMemory;
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, b, th, tw, ntiles, slabs);
-  if (slabs) hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3(14, cdiv(grid, 16)), dim3(256), 0, st, slabs, a.dw, grid);
+  if (slabs) return launch_stem_wgrad_fold(slabs, a.dw, grid, st);
   return hipGetLastError();
 }
 
@@ -988,9 +976,13 @@ static hipError_t launch_stem_wgrad_pool2(const StemWgradArgs& a, const BnBwdArg
     attr_done = true;
   }
   int grid = ntiles < 256 ? ntiles : 256;          // one 12-wave workgroup per CU (143 KiB of LDS)
-  f32x4_t* slabs = grid > 16 ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t))) : nullptr;
+  f32x4_t* slabs = nullptr;
+  if (grid > 1) {
+    slabs = reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t)));
+    if (!slabs) return hipErrorOutOfMemory;
+  }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, st, a, b, th, tw, ntiles, slabs);
-  if (slabs) hipLaunchKernelGGL(stem_wgrad_fold_kernel, dim3(14, cdiv(grid, 16)), dim3(256), 0, st, slabs, a.dw, grid);
+  if (slabs) return launch_stem_wgrad_fold(slabs, a.dw, grid, st);
   return hipGetLastError();
 }
 

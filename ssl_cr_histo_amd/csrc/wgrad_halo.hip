@@ -7,7 +7,8 @@
 // images); per tile it stages the dY tile and ONE (8+2)x(TW+2) input halo (producer BatchNorm+ReLU applied on the way) and
 // all nine taps fetch their B fragments from the halo at shifted pixel addresses -- ds_read_b64_tr_b16 takes a per-lane
 // address, so the shift is free.  4.3x less staging traffic per MAC.  Same 64(kout) x 64(cin) x 9 register tile, wave w
-// owning cin tile w; fp32 hardware atomics into dW.
+// owning cin tile w; the pixel splits' accumulators go to slabs that wgrad_fold_kernel adds into dW in a fixed order.
+#include <cstdio>
 #include <mutex>
 
 #include "kernels.hpp"
@@ -312,58 +313,86 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
 #pragma unroll
     for (int t4 = 0; t4 < 4; ++t4)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < 4; ++j) {               // one pixel split: this workgroup is the only writer of its block of dW
         const int k = k0 + 64 * kh + 16 * t4 + 4 * g + j;
-        atomicAdd(a.dw + ((size_t)k * 9 + t) * a.C + c0 + 16 * wave + li, acc[t][t4][j]);
+        a.dw[((size_t)k * 9 + t) * a.C + c0 + 16 * wave + li] += acc[t][t4][j];
       }
 }
 
-// dW += sum over the pixel splits of the workgroups' accumulator slabs (layout of the store above).  Grid: x = 256-thread
-// blocks over the (kout block, cin block, vector, thread) space, y = chunks of FOLD_Z splits; a thread adds up to FOLD_Z
-// vectors and puts the sum into dW with four fp32 atomics -- 1/FOLD_Z of the atomics the kernel itself would issue, spread
-// over a launch of its own instead of sitting at the end of every workgroup.
-constexpr int FOLD_Z = 16;
-__global__ __launch_bounds__(256) void wgrad_fold_kernel(const f32x4_t* __restrict__ partials, float* dw, int C, int gx, int gy, int splits,
-                                                        int taps, int kh_n) {
-  const int NT = 256 * kh_n, ev = taps * 4;                         // threads per workgroup, accumulator vectors per thread
-  const size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;          // (by, bx, e, tid) flattened, tid fastest
+// dW += sum over the pixel splits of the workgroups' accumulator slabs (layout of the store above), in ONE fixed order: no atomics,
+// so a weight gradient is the same bits run after run (the exact-parity fp32 mode is held to a 24-iteration trajectory, and Adam
+// turns a changed last bit into an lr-sized step).  Block = 64 slab vectors (x) by ZG split lanes (y): split lane y adds the
+// vectors of splits y, y + ZG, ... in rising order, the ZG lane sums are added in lane order by lane 0, which is the only writer of
+// its four dW elements.  mode 0: the (kout block, cin block, tap, thread) layout of wgrad3x3_halo_kernel / wgrad_kernel;
+// mode 1: stem_wgrad's (feature vector f, thread) layout, dW in PyTorch's [64][3][7][7].
+__global__ __launch_bounds__(1024) void wgrad_fold_kernel(const f32x4_t* __restrict__ partials, float* dw, int C, int gx, int gy, int splits,
+                                                         int ev, int kh_n, int mode) {
+  __shared__ f32x4_t red[16][64];
+  const int NT = 256 * kh_n, taps = ev >> 2;                        // threads per workgroup; ev = accumulator vectors per thread
   const size_t per_wg = (size_t)ev * NT;
-  if (v >= (size_t)gx * gy * per_wg) return;
+  const size_t v = (size_t)blockIdx.x * 64 + threadIdx.x;           // (by, bx, e, tid) flattened, tid fastest; the total is a multiple of 64
+  const int ZG = blockDim.y, zl = threadIdx.y;
   const int tid = (int)(v % NT);
   const int e = (int)((v / NT) % ev);
   const int bxy = (int)(v / per_wg);
   const int bx = bxy % gx, by = bxy / gx;
-  const int z0 = blockIdx.y * FOLD_Z, z1 = min(splits, z0 + FOLD_Z);
   f32x4_t sum = {0.f, 0.f, 0.f, 0.f};
-  const f32x4_t* p = partials + (((size_t)z0 * gy + by) * gx + bx) * per_wg + (size_t)e * NT + tid;
   const size_t zstride = (size_t)gy * gx * per_wg;
-  for (int z = z0; z < z1; ++z, p += zstride) {
+  const f32x4_t* p = partials + (size_t)zl * zstride + ((size_t)by * gx + bx) * per_wg + (size_t)e * NT + tid;
+  for (int z = zl; z < splits; z += ZG, p += (size_t)ZG * zstride) {
     const f32x4_t q = __builtin_nontemporal_load(p);
     sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2]; sum[3] += q[3];
   }
+  if (ZG > 1) {
+    red[zl][threadIdx.x] = sum;
+    __syncthreads();
+    if (zl != 0) return;
+    for (int y = 1; y < ZG; ++y) {
+      const f32x4_t q = red[y][threadIdx.x];
+      sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2]; sum[3] += q[3];
+    }
+  }
   const int lane = tid & 63, wave = (tid >> 6) & 3, kh = tid >> 8;
   const int li = lane & 15, g = lane >> 4;
+  if (mode == 1) {
+    const int r = e >> 1, s = (e & 1) * 4 + (li >> 2), c = li & 3;
+    if (s < 7 && c < 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dw[(((16 * wave + 4 * g + j) * 3 + c) * 7 + r) * 7 + s] += sum[j];
+    }
+    return;
+  }
   const int t = e >> 2, t4 = e & 3;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k = bx * 64 * kh_n + 64 * kh + 16 * t4 + 4 * g + j;
-    atomicAdd(dw + ((size_t)k * taps + t) * C + by * 64 + 16 * wave + li, sum[j]);
+    dw[((size_t)k * taps + t) * C + by * 64 + 16 * wave + li] += sum[j];
   }
 }
-hipError_t launch_wgrad_fold(const void* slabs, float* dw, int C, int gx, int gy, int splits, int taps, int kh_n, hipStream_t st) {
-  const size_t nvec = (size_t)gx * gy * taps * 4 * 256 * kh_n;
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)((nvec + 255) / 256), cdiv(splits, FOLD_Z)), dim3(256), 0, st,
-                     reinterpret_cast<const f32x4_t*>(slabs), dw, C, gx, gy, splits, taps, kh_n);
+static hipError_t fold_launch(const void* slabs, float* dw, int C, int gx, int gy, int splits, int ev, int kh_n, int mode, hipStream_t st) {
+  const size_t nvec = (size_t)gx * gy * ev * 256 * kh_n;
+  int zg = 1;                                                       // >= 4 vectors per split lane, at most 16 lanes
+  while (zg < 16 && splits >= 8 * zg) zg *= 2;
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)(nvec / 64)), dim3(64, zg), 0, st, reinterpret_cast<const f32x4_t*>(slabs), dw, C, gx, gy,
+                     splits, ev, kh_n, mode);
   return hipGetLastError();
 }
+hipError_t launch_wgrad_fold(const void* slabs, float* dw, int C, int gx, int gy, int splits, int taps, int kh_n, hipStream_t st) {
+  return fold_launch(slabs, dw, C, gx, gy, splits, taps * 4, kh_n, 0, st);
+}
+// stem form: `nwg` slabs of 14 accumulator vectors x 256 threads
+hipError_t launch_stem_wgrad_fold(const void* slabs, float* dw, int nwg, hipStream_t st) {
+  return fold_launch(slabs, dw, 0, 1, 1, nwg, 14, 1, 1, st);
+}
 
-// slabs of the launches on one stream (a launch's fold has consumed them before the next launch on that stream writes).
-// One entry per stream, 32 entries, least-recently-used eviction: a 33rd stream (virtual-rank tests create a stream per context
+// slabs of the launches on one stream (a launch's fold has consumed them before the next launch on that stream writes; the
+// BatchNorm-backward reduce pass keeps its per-workgroup rows here too).
+// One entry per stream, 64 entries, least-recently-used eviction (logged once: it costs a device synchronise): a 65th stream (virtual-rank tests create a stream per context
 // and drop it) takes over the oldest entry after a device synchronise -- never a silent fall-back to the atomic path, whose
 // summation order differs -- and an evicted or destroyed stream's slab is freed instead of leaking.
 void* wgrad_slabs(hipStream_t st, size_t bytes) {
   struct Slab { hipStream_t st; void* p; size_t cap; unsigned long long used; };
-  constexpr int NSLAB = 32;
+  constexpr int NSLAB = 64;
   static Slab slabs[NSLAB];
   static int n = 0;
   static unsigned long long tick = 0;
@@ -379,6 +408,12 @@ void* wgrad_slabs(hipStream_t st, size_t bytes) {
       e = &slabs[0];
       for (int i = 1; i < NSLAB; ++i)
         if (slabs[i].used < e->used) e = &slabs[i];
+      static bool warned = false;
+      if (!warned) {
+        warned = true;
+        fprintf(stderr, "sslcr: more than %d streams have launched weight-gradient / BatchNorm-backward kernels; the least recently used "
+                        "stream's slab is evicted after a device synchronise (slow when it happens per launch)\n", NSLAB);
+      }
       (void)hipDeviceSynchronize();              // the evicted stream may be gone: wait for the device, not for the stream
       if (e->p) (void)hipFree(e->p);
     }
@@ -412,11 +447,11 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   constexpr int HP = NI * 10 * (TW + 2);
   const int ntiles = (a.N / NI) * (a.H / 8) * (a.W / TW);
   const int kc = (a.K / (64 * KH)) * (a.C / 64);
-  // exactly one resident round: two workgroups per CU.  The pixel split decides how many fp32 atomics hit dW
-  // (workgroups x 64x64x9): with twice as many workgroups the final atomics alone were 22 % of the kernel.
+  // exactly one resident round: two workgroups per CU.  The pixel split decides how many accumulator slabs are written and folded
+  // (workgroups x 64x64x9 floats).
   const int cus = device_cus();
   int splits = cdiv((KH == 1 ? 2 : 1) * cus, kc);        // KH == 2: one 8-wave workgroup per CU
-  const int max_splits = cdiv(ntiles, 16);                // at least 16 tiles per workgroup: below that the fp32 atomics of its 64x64x9 block outweigh the parallelism (RSP N=128: +4 % step)
+  const int max_splits = cdiv(ntiles, 16);                // at least 16 tiles per workgroup: below that the slab of its 64x64x9 block outweighs the parallelism (RSP N=128: +4 % step)
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   const int tps = cdiv(ntiles, splits);
@@ -434,8 +469,12 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int gx = a.K / (64 * KH), gy = a.C / 64;
-  // accumulator slabs + a fold launch instead of atomics from the kernel, when there is more than one split to fold
-  f32x4_t* slabs = (BF && splits > 1) ? reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * 36 * 256 * KH * sizeof(f32x4_t))) : nullptr;
+  // accumulator slabs + the ordered fold when there is more than one split (every dtype)
+  f32x4_t* slabs = nullptr;
+  if (splits > 1) {
+    slabs = reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * 36 * 256 * KH * sizeof(f32x4_t)));
+    if (!slabs) return hipErrorOutOfMemory;        // (no atomic path to fall back to: its summation order would differ)
+  }
   hipLaunchKernelGGL(kern, dim3(gx * gy * splits), dim3(256 * KH), lds, st, a, tps, ntiles, slabs);
   if (slabs) return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, 9, KH, st);
   return hipGetLastError();

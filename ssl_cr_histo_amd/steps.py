@@ -29,8 +29,9 @@ class _Meters:
     far ("one small all-reduce per print_freq"), on the engine's own communicator, and only then syncs to the
     host.  `reduce` is that in-place SUM over ranks (None on one rank), `world` scales the meter weights to global counts."""
 
-    def __init__(self, names, reduce=None, world=1):
+    def __init__(self, names, reduce=None, world=1, device=None):
         self.names = names
+        self.device = device                # where the row-count header lives when no row has been added yet
         self.rows, self.weights = [], []
         self.reduce, self.world = reduce, world
         self.done = []                      # rows already reduced and fetched: python lists
@@ -40,12 +41,29 @@ class _Meters:
         self.weights.append(n * self.world)
 
     def meters(self, acc_denoms=None):
+        """COLLECTIVE on sharded runs: every rank must call it at the same points with the same number of rows gathered since
+        its last call (the step functions do: print_freq boundaries and epoch end of equally long loaders).  A rank whose loader
+        is shorter would otherwise reduce a buffer of another length -- a hang or mismatched sums -- so a fixed-size header with
+        the row count is reduced first and a disagreement raises on every rank."""
         out = {k: AverageMeter() for k in self.names}
+        if self.reduce is not None:
+            # (n // 4096, n % 4096) and their squares: all ranks hold the same n  <=>  W * sum(a^2) == (sum a)^2 for both
+            # digits (Cauchy-Schwarz with equality); every value is exact in fp32 for n < 2^24
+            n = len(self.rows)
+            a, b = float(n // 4096), float(n % 4096)
+            dev = self.rows[0].device if self.rows else self.device
+            hdr = torch.tensor([a, a * a, b, b * b], dtype=torch.float32, device=dev)
+            self.reduce(hdr)
+            sa, qa, sb, qb = hdr.cpu().tolist()
+            if qa * self.world != sa * sa or qb * self.world != sb * sb:
+                raise RuntimeError(f"_Meters.meters(): the ranks gathered different numbers of steps since the last read (this rank "
+                                   f"{n}, mean over ranks {(sa * 4096 + sb) / self.world:g}): the loaders' lengths differ, or "
+                                   f"meters() was not called on every rank")
         if self.rows:
             vals = torch.stack(self.rows)
             if self.reduce is not None:
-                self.reduce(vals)                                  # the one collective per print / epoch boundary
-            self.done += vals.cpu().tolist()                       # the single device->host sync
+                self.reduce(vals)                                  # the one data collective per print / epoch boundary
+            self.done += vals.cpu().tolist()                       # the device->host sync
             self.rows = []
         for r, n in zip(self.done, self.weights):
             for k in self.names:
@@ -57,7 +75,7 @@ class _Meters:
 
 
 def _meters(eng, names):
-    return _Meters(names, eng.all_reduce_sum if eng.world > 1 else None, eng.world)
+    return _Meters(names, eng.all_reduce_sum if eng.world > 1 else None, eng.world, eng.device)
 
 
 def _prefetch_on(args):

@@ -28,7 +28,14 @@ except FileNotFoundError:
 
 def bound_for(key, ceiling, floor=0.0):
     m = MEASURED.get(key)
-    return ceiling if m is None else min(ceiling, max(2.0 * m, floor))
+    if m is None:
+        # a key without a recorded value used to fall back to the (generous) ceiling silently; now it is an error unless this
+        # run is the one that records it
+        if os.environ.get("SSLCR_RECORD_ERRORS"):
+            return ceiling
+        raise AssertionError(f"{key}: no measured value in tests/measured_errors.json -- run the GPU suite once with "
+                             f"SSLCR_RECORD_ERRORS=<file> and merge it with tools/update_measured.py")
+    return min(ceiling, max(2.0 * m, floor))
 
 
 def held(key, err, ceiling, floor=0.0, what=""):

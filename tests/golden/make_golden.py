@@ -543,6 +543,125 @@ def gen_traj(name, out):
     snapshot(name, ms, cs, out)
 
 
+def _traj_run_reference(name, threads):
+    """the reference's own 24 train() calls of gen_traj at a given thread count -> (rets [iters][3], vals [iters/4], state_dict)"""
+    c = C.CASES[name]
+    cam = c["script"] == "cam_cr"
+    m = importlib.import_module("eval_Camelyon_SSL_CR" if cam else "eval_BreastPathQ_SSL_CR")
+    torch.set_num_threads(threads)
+    try:
+        mt, ct = build("finetune", "finetune", c["classes"], rand_stats=True)
+        ms, cs = build("finetune", "finetune", c["classes"], rand_stats=True)
+        freeze(mt, 64)
+        freeze(ms, c["modules"])
+        prm = filter(lambda p: p.requires_grad, list(ms.parameters()) + list(cs.parameters()))
+        if cam:
+            opt = torch.optim.SGD(prm, lr=c["lr"], momentum=0.9, weight_decay=c["wd"], nesterov=True)
+        else:
+            opt = torch.optim.Adam(prm, lr=c["lr"], betas=(0.9, 0.999), weight_decay=c["wd"])
+        rets, vals = [], []
+        torch.manual_seed(780)
+        for it in range(c["iters"]):
+            if cam:
+                r = m.train(args_ns(lambda_u=c["lambda_u"], image_size=c["hw"]), mt, ms, ct, cs,
+                            C.labeled_batches_cls(name, 1000 + 7 * it, 1), C.labeled_batches_cls(name, 1100 + 7 * it, 0),
+                            C.unlabeled_batches(name, 2000 + 7 * it), C.unlabeled_batches(name, 2100 + 7 * it), opt, 1)
+            else:
+                r = m.train(args_ns(lambda_u=c["lambda_u"]), mt, ms, ct, cs, C.labeled_batches(name, 1000 + 7 * it),
+                            C.unlabeled_batches(name, 2000 + 7 * it), opt, 1)
+            rets.append(r[:3])
+            if (it + 1) % 4 == 0:
+                if cam:
+                    v = m.validate(args_ns(), ms, cs, C.val_batches_cls(name, 4000, 1), C.val_batches_cls(name, 4100, 0), 1)[0]
+                else:
+                    v = m.validate(args_ns(), ms, cs, C.val_batches_reg(name), 1)
+                vals.append(v)
+        sd = {k: v.detach().double().clone() for mod in (ms, cs) for k, v in mod.state_dict().items() if "num_batches" not in k}
+    finally:
+        torch.set_num_threads(8)
+    return np.array(rets, dtype=np.float64), np.array(vals, dtype=np.float64), sd
+
+
+def _traj_run_f64(name):
+    """the same 24 iterations in FLOAT64 through the oracle restatement (the reference's train() casts its inputs to float32, so
+    it cannot run in double itself; the oracle is held to 2e-4 of it by tests/test_oracle_golden.py).  Same seeds, same shuffles
+    (torch.manual_seed(780); three randperms per Camelyon train() call, one per validate(): eval_Camelyon_SSL_CR.py:79-81,184)."""
+    from oracle import steps as S
+    c = C.CASES[name]
+    cam = c["script"] == "cam_cr"
+    kind = "ce" if cam else "mse"
+    ps, bs = _oracle_params("finetune", c["classes"], torch.float64, True)
+    pt, bt = _oracle_params("finetune", c["classes"], torch.float64, True)
+    for v in pt.values():
+        v.requires_grad_(False)
+    S.apply_freeze(ps, c["modules"])
+    prm = [v for v in ps.values() if v.requires_grad]
+    opt = S.SGDNesterov(prm, c["lr"], 0.9, c["wd"]) if cam else S.Adam(prm, c["lr"], (0.9, 0.999), 1e-8, c["wd"])
+    hw = c["hw"]
+    rets, vals = [], []
+    torch.manual_seed(780)
+
+    def one(loader):
+        (b,) = list(loader)
+        return b
+    for it in range(c["iters"]):
+        if cam:
+            (tx, ty), (nx_, ny) = one(C.labeled_batches_cls(name, 1000 + 7 * it, 1)), one(C.labeled_batches_cls(name, 1100 + 7 * it, 0))
+            (tuw, tus), (nuw, nus) = one(C.unlabeled_batches(name, 2000 + 7 * it)), one(C.unlabeled_batches(name, 2100 + 7 * it))
+            tx = tx.reshape(-1, 3, hw, hw); nx_ = nx_.reshape(-1, 3, hw, hw)
+            ty = ty.reshape(-1).long(); ny = ny.reshape(-1).long()
+            p_x, p_uw, p_us = torch.randperm(2 * len(tx)), torch.randperm(2 * len(tuw)), torch.randperm(2 * len(tus))
+            x, y = torch.cat([tx, nx_])[p_x].double(), torch.cat([ty, ny])[p_x]
+            u_w, u_s = torch.cat([tuw, nuw])[p_uw].double(), torch.cat([tus, nus])[p_us].double()
+        else:
+            (x, y), (u_w, u_s) = one(C.labeled_batches(name, 1000 + 7 * it)), one(C.unlabeled_batches(name, 2000 + 7 * it))
+            x, y, u_w, u_s = x.reshape(-1, 3, 256, 256).double(), y.double().reshape(-1), u_w.double(), u_s.double()
+        r = S.ssl_cr_step(kind, ps, bs, pt, bt, opt, x, y, u_w, u_s, c["lambda_u"], True)
+        rets.append((r["loss"], r["loss_x"], r["loss_u"]))
+        if (it + 1) % 4 == 0:
+            meter = S.AverageMeter()                      # the validate() loops: loss averaged with the batch size as weight
+            if cam:
+                for (tx, ty), (nx_, ny) in zip(C.val_batches_cls(name, 4000, 1), C.val_batches_cls(name, 4100, 0)):
+                    perm = torch.randperm(2 * len(tx))
+                    yv = torch.cat([ty, ny])[perm].long()
+                    v = S.supervised_step("ce", ps, bs, None, torch.cat([tx, nx_])[perm].double(), yv, True, train=False)
+                    meter.update(v["loss"], yv.size(0))
+            else:
+                for x, y in C.val_batches_reg(name):
+                    v = S.supervised_step("mse", ps, bs, None, x.double(), y.double(), True, train=False)
+                    meter.update(v["loss"], y.size(0))
+            vals.append(meter.avg)
+    sd = {k: v.detach().double().clone() for d in (ps, bs) for k, v in d.items() if "num_batches" not in k}
+    return np.array(rets, dtype=np.float64), np.array(vals, dtype=np.float64), sd
+
+
+def gen_traj_yard(name, out):
+    """Yardstick for test_trajectory_vs_reference's fp32 bounds (tests/golden/traj_*_yard.npz, beside the unchanged traj_*.npz).
+    A 24-iteration Adam / SGD trajectory amplifies round-off, so "how far may a correct fp32 implementation be from the
+    reference's numbers" is measured here instead of asserted: the trajectory in float64 (oracle restatement) and the reference's
+    own fp32 run at 8, 3 and 1 threads (torch-CPU splits its reductions by thread count: three valid fp32 summation orders).
+    Stored: per-iteration losses, validate() values and per-tensor state norms of every run.  The test bounds the engine's distance
+    from float64 by 3 x the largest distance of a reference fp32 run from float64 (never below 1e-3)."""
+    base = name[:-5]
+    r64, v64, s64 = _traj_run_f64(base)
+    out[f"{name}/ret"] = r64                    # (main() prints this key)
+    out[f"{name}/ret_f64"], out[f"{name}/vals_f64"] = r64, v64
+    names = list(s64.keys())
+    out[f"{name}/names"] = np.array(names)
+    out[f"{name}/l2_f64"] = np.array([float(s64[k].norm()) for k in names])
+    for k in ("model.layer4.1.bn2.running_mean", "model.bn1.running_mean"):
+        out[f"{name}/t_f64/{k}"] = s64[k].numpy().copy()
+    for th in (8, 3, 1):
+        r, v, sd = _traj_run_reference(base, th)
+        out[f"{name}/ret_t{th}"], out[f"{name}/vals_t{th}"] = r, v
+        # relative distance of this fp32 run's final state from the float64 one, per tensor: ||a - b|| / ||b||
+        out[f"{name}/state_err_t{th}"] = np.array([float((sd[k] - s64[k]).norm() / (s64[k].norm() + 1e-300)) for k in names])
+        for k in ("model.layer4.1.bn2.running_mean", "model.bn1.running_mean"):
+            out[f"{name}/t_t{th}/{k}"] = sd[k].numpy().copy()
+        print(f"  {name} t{th}: max loss dev vs f64 {np.abs(r / r64 - 1).max():.3e}, validate {np.abs(v / v64 - 1).max():.3e}, "
+              f"state {out[f'{name}/state_err_t{th}'].max():.3e}")
+
+
 # ---------------------------------------------------------------- checkpoint layouts (row f2)
 def tree_struct(obj, path=""):
     """JSON-able description of a checkpoint: containers with their types and key order, tensors as (dtype, shape, path),
@@ -821,6 +940,7 @@ def main():
             "kather_cr_f0": gen_kather_cr, "rsp": gen_rsp, "cam_sup": gen_cam_sup, "bpq_sup": gen_bpq_sup,
             "cam_wsi": gen_cam_wsi, "cam_wsi_large": gen_cam_wsi, "bpq_cr_full": gen_bpq_cr_full, "rsp_full": gen_rsp_full, "cam_cr_full": gen_cam_cr_full,
             "kather_sup": gen_kather_sup, "kather_sup_full": gen_kather_sup_full, "traj_bpq_cr": gen_traj, "traj_cam_cr": gen_traj,
+            "traj_bpq_cr_yard": gen_traj_yard, "traj_cam_cr_yard": gen_traj_yard,
             "ckpt_bpq_cr": gen_ckpt_bpq_cr, "ckpt_cam_sup": gen_ckpt_cam_sup, "ckpt_rsp": gen_ckpt_rsp}
     only = sys.argv[1:]
     for name, fn in gens.items():

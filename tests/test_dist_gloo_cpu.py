@@ -61,11 +61,70 @@ def _worker(rank, world, port, q):
     for sh in share:
         m.add(sh, 4)                                          # 4 labeled images per rank and step -> global count 8
     out = m.meters()
-    assert calls == [(2, 4)], calls                           # one collective for both steps
+    assert calls == [(4,), (2, 4)], calls                     # the row-count header, then ONE collective for both steps
     assert abs(out["loss"].avg - (0.9 + 1.8) / 2) < 1e-6 and abs(out["acc"].avg - (6.0 / 8 + 3.0 / 8) / 2) < 1e-6
     m.add(share[0], 4)
     out = m.meters()                                          # a later read reduces only the new row
-    assert calls == [(2, 4), (1, 4)] and abs(out["loss"].avg - (0.9 + 1.8 + 0.9) / 3) < 1e-6
+    assert calls == [(4,), (2, 4), (4,), (1, 4)] and abs(out["loss"].avg - (0.9 + 1.8 + 0.9) / 3) < 1e-6
+    # ranks that gathered different numbers of steps (loaders of different length): the header catches it on EVERY rank before
+    # the rows -- buffers of different lengths -- would meet in a collective
+    for _ in range(rank + 1):
+        m.add(share[0], 4)
+    try:
+        m.meters()
+        raise AssertionError("a row-count mismatch across ranks went unnoticed")
+    except RuntimeError as e:
+        assert "different numbers of steps" in str(e)
+    assert calls[-1] == (4,)                                  # only the header was reduced
+    # 5. the engine side of the sharded path with world = 2: dist.attach_engine -> Engine.init_comm (unique id made on rank 0,
+    #    broadcast over the process group, sslcr_comm_init with this rank / world on every rank) -> steps._meters(engine) ->
+    #    Engine.all_reduce_sum -> sslcr_comm_all_reduce_f32.  No GPU here, so the four C-ABI entry points are a stub with the
+    #    header's signatures (include/sslcr.h) whose all-reduce runs over gloo; the engine object is the real class.
+    import ctypes
+    from ssl_cr_histo_amd import _lib as L
+    from ssl_cr_histo_amd import engine as E
+    from ssl_cr_histo_amd import steps as ST
+    log = []
+
+    class Stub:
+        def sslcr_comm_unique_id(self, buf):
+            ident = bytes((7 * i + 3) % 251 for i in range(256))      # two 128-byte ids, as sslcr_comm_unique_id documents
+            ctypes.memmove(buf, ident, 256)
+            log.append(("unique_id", rank))
+            return 0
+
+        def sslcr_comm_init(self, handle, buf, r, w):
+            log.append(("init", bytes(buf), r, w))
+            self.rank, self.world = r, w
+            return 0
+
+        def sslcr_comm_info(self, handle, pr, pw, pt):
+            pr._obj.value, pw._obj.value, pt._obj.value = self.rank, self.world, 1
+            return 0
+
+        def sslcr_comm_all_reduce_f32(self, handle, ptr, n, stream):
+            addr = ptr.value if isinstance(ptr, ctypes.c_void_p) else int(ptr)
+            t = torch.frombuffer((ctypes.c_float * n).from_address(addr), dtype=torch.float32)
+            dist.all_reduce(t)
+            log.append(("all_reduce", n))
+            return 0
+    stub = Stub()
+    L.lib = lambda: stub
+    L.stream_ptr = lambda: None
+    eng = E.Engine.__new__(E.Engine)                          # (Engine() itself refuses to exist without a GPU: tests/test_abi_cpu.py)
+    eng.handle, eng.device, eng.rank, eng.world = ctypes.c_void_p(1), torch.device("cpu"), 0, 1
+    assert sd.attach_engine(eng) is eng
+    assert (eng.rank, eng.world) == (rank, world) and eng.comm_info() == (rank, world, "rccl")
+    want_id = bytes((7 * i + 3) % 251 for i in range(256))
+    assert [e for e in log if e[0] == "init"] == [("init", want_id, rank, world)]      # rank 1 received rank 0's id
+    assert (("unique_id", 0) in log) == (rank == 0)           # only rank 0 asks the library for an id
+    mm = ST._meters(eng, ["loss", "loss_x", "loss_u", "acc"])
+    assert mm.world == world and mm.reduce is not None
+    rows = sd.shard_batch(torch.tensor([[0.3, 0.1, 0.2, 2.0], [0.6, 0.2, 0.4, 1.0]]), rank, world)    # one step's share per rank
+    mm.add(rows[0].clone(), 4)
+    out = mm.meters()
+    assert abs(out["loss"].avg - 0.9) < 1e-6 and abs(out["acc"].avg - 3.0 / 8) < 1e-6
+    assert [e for e in log if e[0] == "all_reduce"] == [("all_reduce", 4), ("all_reduce", 4)]          # header + one row
     q.put((rank, "ok"))
     dist.destroy_process_group()
 

@@ -254,7 +254,8 @@ def test_checkpoint_pretrain_resume_continues_like_the_reference(dtype, tmp_path
 def test_trajectory_vs_reference(name, dtype):
     """24 consecutive iterations of the reference's own train() (one call per iteration, one optimizer object, 256x256, full
     fine-tune; Adam / MSE for BreastPathQ, SGD-Nesterov / CE + pseudo-label CE for Camelyon), per-iteration returned losses,
-    validate() every 4 iterations, final snapshot.  fp32 mode is held to the north-star 1e-3 on EVERY iteration's losses.
+    validate() every 4 iterations, final snapshot.  fp32 mode is held, against the FLOAT64 trajectory, to 3 x the distance of the
+    reference's own fp32 runs from float64 (tests/golden/traj_*_yard.npz; never below the north-star 1e-3).
     bf16 mode (the mode the throughput is quoted in) is measured, printed and bounded: every iteration's losses within 3e-2 of the
     reference's, and the deviation must not keep growing -- the mean of the last eight iterations may not exceed 1.3 x the mean of
     iterations 9-16 (+0.2 %).  Measured: SGD-Nesterov / Camelyon stays at 0.3-2.5e-3 throughout; Adam / BreastPathQ (where every
@@ -271,7 +272,7 @@ def test_trajectory_vs_reference(name, dtype):
     freeze(ms, c["modules"])
     opt = _opt_for(c, ms, cs)
     want, wvals = g[f"{name}/ret"], g[f"{name}/vals"]
-    dev, vdev = [], []
+    dev, vdev, rets, vgot = [], [], [], []
     torch.manual_seed(780)
     for it in range(c["iters"]):
         if cam:
@@ -282,6 +283,7 @@ def test_trajectory_vs_reference(name, dtype):
             r = steps.bpq_cr_train(ns(lambda_u=c["lambda_u"]), mt, ms, ct, cs, C.labeled_batches(name, 1000 + 7 * it),
                                    C.unlabeled_batches(name, 2000 + 7 * it), opt, 1)
         dev.append(max(abs(r[i] - want[it][i]) / abs(want[it][i]) for i in range(3)))
+        rets.append([float(r[i]) for i in range(3)])
         if cam and dtype == "fp32":
             assert abs(r[3] - want[it][3]) <= 1.0 / 6 + 1e-9, (it, r[3], want[it][3])       # accuracy over 6 labeled images
         if (it + 1) % 4 == 0:
@@ -290,17 +292,53 @@ def test_trajectory_vs_reference(name, dtype):
             else:
                 v = (steps.bpq_cr_validate(ns(), ms, cs, C.val_batches_reg(name), 1),)
             vdev.append(abs(v[0] - wvals[len(vdev)][0]) / abs(wvals[len(vdev)][0]))
+            vgot.append(float(v[0]))
     print(f"[{dtype}] {name}: per-iteration max relative loss deviation from the reference:\n   " + " ".join(f"{d:.2e}" for d in dev) +
           "\n   validate() after every 4th iteration: " + " ".join(f"{d:.2e}" for d in vdev))
     if dtype == "fp32":
-        assert max(dev) <= 1e-3, dev
-        assert max(vdev) <= 5e-3, vdev
-        # 5e-2 on the state: a conv weight in front of a BatchNorm has directions the loss does not depend on (scale, per-channel
-        # offset); their true gradient is zero, what two fp32 implementations compute there is round-off of opposite sign, and
-        # Adam turns any nonzero gradient into a step of size lr -- so pre-BatchNorm means (running_mean) drift apart by ~lr per
-        # iteration while the training losses stay within 6e-4 and validate() within 5e-3 (measured on layer4.1.bn2.running_mean:
-        # 1e-2 after 12 iterations, 2.2e-2 after 24)
-        check_snapshot(g, name, state_of(ms, cs), 5e-2)
+        # What may a correct fp32 implementation deviate by after 24 optimizer steps?  Measured, not asserted: traj_*_yard.npz
+        # (tests/golden/make_golden.py:gen_traj_yard) holds the trajectory in FLOAT64 and the reference's own fp32 run at 8, 3
+        # and 1 threads (three valid fp32 summation orders).  The engine is held, against float64, to 3 x the largest distance
+        # of a reference fp32 run from float64 (never below the north-star 1e-3) -- on every iteration's losses, on validate()
+        # and on the final state.  (Adam / BreastPathQ: the reference's own validate() sits 2.8e-3 from float64 after FOUR
+        # iterations and its per-iteration losses 9.6e-4 after 24; until round 4 this test held the engine to a constant 5e-3
+        # against ONE of those fp32 runs and failed at 5.6e-3 on the driver's box.)
+        y = load_golden(name + "_yard")
+        yn = name + "_yard"
+        r64, v64 = y[f"{yn}/ret_f64"], y[f"{yn}/vals_f64"]
+        assert np.array_equal(y[f"{yn}/ret_t8"], want[:, :3]) and np.array_equal(y[f"{yn}/vals_t8"], wvals[:, 0])   # same reference run
+        yard_ret = max(float(np.abs(y[f"{yn}/ret_t{t}"] / r64 - 1).max()) for t in (8, 3, 1))
+        yard_val = max(float(np.abs(y[f"{yn}/vals_t{t}"] / v64 - 1).max()) for t in (8, 3, 1))
+        dev64 = [max(abs(rets[it][i] - r64[it][i]) / abs(r64[it][i]) for i in range(3)) for it in range(c["iters"])]
+        vdev64 = [abs(vgot[i] - v64[i]) / abs(v64[i]) for i in range(len(vgot))]
+        print(f"   vs float64: losses max {max(dev64):.2e} (reference fp32 runs: {yard_ret:.2e}), validate() max {max(vdev64):.2e} "
+              f"(reference fp32 runs: {yard_val:.2e})")
+        b_ret, b_val = max(3.0 * yard_ret, 1e-3), max(3.0 * yard_val, 1e-3)
+        held(f"{name}/iter_max_f64/fp32", max(dev64), b_ret, floor=b_ret)           # (recorded; the bound is the yardstick's)
+        held(f"{name}/val_max_f64/fp32", max(vdev64), b_val, floor=b_val)
+        # ... and against the fp32 golden itself (two fp32 runs, each up to `yard` from float64)
+        assert max(dev) <= max(1e-3, 4.0 * yard_ret), dev
+        assert max(vdev) <= max(1e-3, 4.0 * yard_val), vdev
+        # final state: per-tensor norms against float64, each within 3 x the reference fp32 runs' own relative distance
+        # ||a - a64|| / ||a64|| for that tensor (a conv weight in front of a BatchNorm has directions the loss does not depend
+        # on; their gradient is round-off, Adam turns it into lr-sized steps, and the pre-BatchNorm running means drift: 2.3e-2
+        # on layer4.1.bn1.running_mean between the reference's own fp32 run and float64)
+        names = [str(n) for n in y[f"{yn}/names"]]
+        st = state_of(ms, cs)
+        yard_state = np.max(np.stack([y[f"{yn}/state_err_t{t}"] for t in (8, 3, 1)]), axis=0)
+        worst = 0.0
+        for i, k in enumerate(names):
+            got = float(st[k].double().norm())
+            e = abs(got - y[f"{yn}/l2_f64"][i]) / (y[f"{yn}/l2_f64"][i] + 1e-300)
+            assert e <= max(3.0 * yard_state[i], 1e-3), (k, e, yard_state[i])
+            worst = max(worst, e / max(yard_state[i], 1e-12))
+        for k in ("model.layer4.1.bn2.running_mean", "model.bn1.running_mean"):
+            a64 = torch.from_numpy(y[f"{yn}/t_f64/{k}"])
+            e = float((st[k].double() - a64).norm() / a64.norm())
+            ref = max(float((torch.from_numpy(y[f"{yn}/t_t{t}/{k}"]) - a64).norm() / a64.norm()) for t in (8, 3, 1))
+            print(f"   {k}: engine {e:.2e} from float64, reference fp32 runs {ref:.2e}")
+            assert e <= max(3.0 * ref, 1e-3), (k, e, ref)
+        check_snapshot(g, name, st, max(1e-3, 4.0 * float(yard_state.max())))
     else:
         # every iteration within 2 x the LARGEST per-iteration deviation measured over the trajectory (tests/measured_errors.json;
         # which iteration carries the maximum moves with any change of summation order, the maximum itself does not), ceiling 3e-2

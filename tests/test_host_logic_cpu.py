@@ -199,6 +199,15 @@ def test_colour_op_restatements_and_draw_orders():
     assert [A.colour_shifts(ra) for _ in range(5)] == [AR.draw_colour_shifts(rb) for _ in range(5)]
     assert [A.brightness_contrast_params(ra, contrast_limit=0.1) for _ in range(8)] == \
            [AR.draw_brightness_contrast(rb, contrast_limit=0.1) for _ in range(8)]
+    # a NEGATIVE limit (RandAugment's val for v < 15, models/randaugment.py:93-103): albumentations 0.1.8 keeps the tuple
+    # (-limit, limit) unsorted, so the draw is uniform(|v|, -|v|) = |v| (1 - 2 r) -- the mirror image of the sorted draw
+    rc = random.Random(9)
+    on, alpha, beta = A.brightness_contrast_params(rc, contrast_limit=-0.1)
+    rd = random.Random(9)
+    rd.random(); rd.random()
+    r = rd.random()
+    assert on and abs(alpha - (1.0 + 0.1 * (1 - 2 * r))) < 1e-15 and A.brightness_contrast_params(random.Random(9), contrast_limit=-0.1) == \
+        AR.draw_brightness_contrast(random.Random(9), contrast_limit=-0.1)
     dark = (img // 2).astype(np.uint8)
     out = AR.brightness_contrast_adjust(dark, 1.2, 0.2)
     assert out.max() == dark.max() and out.dtype == np.uint8
