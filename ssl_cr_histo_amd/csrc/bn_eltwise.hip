@@ -810,8 +810,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_sums_kernel(const double* __restr
   const bool ok = v < C2;
   const double* p = rows + ((size_t)blockIdx.y * nrows) * C2 + v;
   double s = 0.0;
-  if (ok)
-    for (int r = yl; r < nrows; r += 16) s += p[(size_t)r * C2];
+  if (ok) {
+#pragma unroll 8
+    for (int r = yl; r < nrows; r += 16) s += __builtin_nontemporal_load(p + (size_t)r * C2);     // (loads independent: all in flight at once)
+  }
   red[yl][threadIdx.x] = s;
   __syncthreads();
   if (yl != 0 || !ok) return;

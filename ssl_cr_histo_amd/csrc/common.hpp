@@ -114,6 +114,52 @@ __device__ __forceinline__ void row16_sum4(float& a, float& b, float& c, float& 
       "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
       : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
+// Sums of SIXTEEN values over the 16 lanes of a DPP row in 32 instructions (row16_sum: 16 x 4 fused, 128 as the compiler emits
+// them): a reduction tree that halves the VALUES a lane carries while it doubles the lanes they cover.  Step 1 pairs lane i with
+// i ^ 8 (row_ror:8): lanes 0-7 add up values 0-7, lanes 8-15 values 8-15 (the partner's copy of the same register) -- the two
+// halves are the DPP bank masks 0x3 / 0xc, so no select is needed and the result lands in v[0..7] for every lane.  Step 2 pairs
+// a lane with its mirror in the half row (row_half_mirror, which flips lane bit 2: banks 0x5 / 0xa) -> v[0..3]; steps 3-4 are the
+// two quad exchanges on those four.  Afterwards lane l holds in v[0..3] the complete sums of values 4 (l >> 2) + 0..3: quad q of the
+// row owns values 4q..4q+3 (all four lanes of the quad hold the same four).  Every DPP read is >= 3 instructions behind the write
+// of its register (the hardware wants two wait states); the leading s_nop covers the compiler's instruction in front.
+__device__ __forceinline__ void row16_fold16(float (&v)[16]) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %0, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %1, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %2, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %3, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %4, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %5, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %6, %14, %14 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %7, %7, %7 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+      "v_add_f32_dpp %7, %15, %15 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %2, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %3, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+      : "v"(v[8]), "v"(v[9]), "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15]));
+}
 // full 64-lane sum, result valid in every lane
 __device__ __forceinline__ float wave_sum(float v) {
   v = row16_sum(v);

@@ -74,7 +74,8 @@ __device__ unsigned long long g_h16_prof[16][8];
 //     the ring, the short 8-MFMA steps of this shape left the HBM round trip of the halo half exposed and paid 8 barriers
 //     per 144 MFMAs.
 template <typename T, int BKO, int WK, bool XF, bool WR>
-__global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items, const int kshift) {
+__global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items, const int kshift,
+                                                                  const int flags) {
   constexpr int NT = 256 * WK;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int CE = 8 * EPC;                 // channels per 128-byte slab
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
     if (mk) { s_msh[i] = a.mask_shift[mo]; s_mmu[i] = a.mask_mean[mo]; }
   }
   const float relu_lo = a.in_relu ? 0.f : -__builtin_inff();
+  const float out_lo = a.relu ? 0.f : -__builtin_inff();
 
   // XCD-aware walk: blocks land on XCD (blockIdx % 8); each XCD takes a contiguous run of tiles per round so that
   // neighbouring tiles' shared halo rows hit the same L2.
@@ -300,6 +302,9 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
     return ((((size_t)q.n0 * a.H + h) * a.W + w) * a.K + q.k0 + wk * (BKO / WK) + g * (4 * TK)) * sizeof(T);
   };
   int wb = 0, item = first, slab = 0;
+  // static priority for the second-dispatched half of the workgroup (flags bit 0): the two waves of a SIMD are arbitrated by
+  // priority, then age, and waves 4-7 lose every contended issue slot to waves 0-3 (MI355X_MICROARCH.md, "Two waves per SIMD")
+  if ((flags & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
 #ifdef SSLCR_H16_PROF
   unsigned long long h16_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long h16_begin = __builtin_readcyclecounter();
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
             st16(yg + off + q * 16, PackH<T>::run(vq));
           }
 #pragma unroll
-          for (int e = 0; e < EPC; ++e) { s1[q * EPC + e] = row16_sum(a1[e]); s2[q * EPC + e] = row16_sum(a2[e]); }
+          for (int e = 0; e < EPC; ++e) { s1[q * EPC + e] = a1[e]; s2[q * EPC + e] = a2[e]; }
         }
       } else {
       float bias[4 * TK];
@@ -458,10 +463,9 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
 #pragma unroll
             for (int e = 0; e < EPC; ++e) vq[e] += rr[e];
           }
-          if (a.relu) {
+          // (one v_med3 per value; written as `if (a.relu) fmaxf` the compiler if-converted it to a compare + select pair)
 #pragma unroll
-            for (int e = 0; e < EPC; ++e) vq[e] = fmaxf(vq[e], 0.f);
-          }
+          for (int e = 0; e < EPC; ++e) vq[e] = clamp_lo(vq[e], out_lo);
           st16(yg + off + q * 16, PackH<T>::run(vq));
         }
       }
@@ -473,13 +477,36 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
             float x1 = 0.f, x2 = 0.f;
 #pragma unroll
             for (int p = 0; p < TP; ++p) { float q = acc[t][p][j]; x1 += q; x2 = fmaf(q, q, x2); }
-            s1[t * 4 + j] = row16_sum(x1);
-            s2[t * 4 + j] = row16_sum(x2);
+            s1[t * 4 + j] = x1;
+            s2[t * 4 + j] = x2;
           }
       }
       }
+      // s1 / s2: this lane's sums over its four pixel rows; now over the 16 pixel columns (the lanes of a DPP row)
+      constexpr bool FOLD = 4 * TK == 16;
       if (a.stats) {
-        if (li == 0) {
+        if constexpr (FOLD) {
+          // quad q of the row ends up with the sums of kouts 4q..4q+3 in s[0..3] (row16_fold16: 32 DPP adds per 16 values where
+          // 16 row16_sum calls are 128 instructions as compiled); its first lane adds them into the workgroup's running sums
+          row16_fold16(s1);
+          row16_fold16(s2);
+          if ((li & 3) == 0) {
+            float* sp = s_stat + (wp * 2) * BKO + wk * (BKO / WK) + g * (4 * TK) + (li >> 2) * 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float* sv = h ? s2 : s1;
+              f32x4_t* slot = reinterpret_cast<f32x4_t*>(sp + h * BKO);
+              f32x4_t v = *slot;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += sv[e];
+              *slot = v;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4 * TK; ++i) { s1[i] = row16_sum(s1[i]); s2[i] = row16_sum(s2[i]); }
+        }
+        if (!FOLD && li == 0) {
           // each (wave row, kout) entry has exactly one writer LANE in the workgroup, so the running sums are updated with plain
           // 16-byte reads and writes: the 8 * TK LDS float atomics this replaces held the LDS pipe ~40 cycles each (measured on the
           // ping-pong form, tools/microbench/pp64_phase_bench.hip: 1400 -> 250 cycles per tile)
@@ -582,13 +609,19 @@ static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
   const int grid = h16_grid(a, BKO);                                    // one 8-wave workgroup per CU
   const int kbn = a.K / BKO, gseg = grid / nseg;
   const int kshift = (kbn > 1 && (kbn & (kbn - 1)) == 0 && (gseg & (kbn - 1)) == 0) ? __builtin_ctz(kbn) : -1;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WK), lds, st, a, tiles, n_items, kshift);
+  static const int flags = [] { const char* e = getenv("SSLCR_H16_PRIO"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WK), lds, st, a, tiles, n_items, kshift, flags);
   return hipGetLastError();
 }
 
 template <typename T>
 static hipError_t launch_ht(const ConvArgs& a, hipStream_t st) {
   const bool xf = a.in_scale != nullptr;
+  if constexpr (sizeof(T) == 2) {
+    // ping-pong form with the refilled filter bank (conv_ppr.hip): the 128- / 256-channel shapes
+    const int hg = h16_grid(a, a.K % 128 == 0 ? 128 : 64);
+    if (conv_ppr_ok(DT_BF16, a, hg)) return launch_conv_ppr(a, hg, st);
+  }
   if (a.K % 128 == 0) return xf ? launch_h<T, 128, 2, true>(a, st) : launch_h<T, 128, 2, false>(a, st);
   if constexpr (sizeof(T) == 2)
     if (h16_resident(a)) {
@@ -605,6 +638,7 @@ hipError_t launch_conv_h16(int dtype, const ConvArgs& a, hipStream_t st) {
 
 const char* conv_h16_name(int dtype, const ConvArgs& a) {
   const bool bf = dtype == DT_BF16, xf = a.in_scale != nullptr;
+  if (bf && conv_ppr_ok(DT_BF16, a, h16_grid(a, a.K % 128 == 0 ? 128 : 64))) return conv_ppr_name(a);
   if (a.K % 128 == 0) {
     if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, true, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, false, false>";
     return xf ? "sslcr::conv3x3_h16_kernel<float, 128, 2, true, false>" : "sslcr::conv3x3_h16_kernel<float, 128, 2, false, false>";

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
 
 // dW += sum over the pixel splits of the workgroups' accumulator slabs (layout of the store above), in ONE fixed order: no atomics,
 // so a weight gradient is the same bits run after run (the exact-parity fp32 mode is held to a 24-iteration trajectory, and Adam
-// turns a changed last bit into an lr-sized step).  Block = 64 slab vectors (x) by ZG split lanes (y): split lane y adds the
+// turns a changed last bit into an lr-sized step).  Block = 16 / 32 / 64 slab vectors (x) by ZG split lanes (y): split lane y adds the
 // vectors of splits y, y + ZG, ... in rising order, the ZG lane sums are added in lane order by lane 0, which is the only writer of
 // its four dW elements.  mode 0: the (kout block, cin block, tap, thread) layout of wgrad3x3_halo_kernel / wgrad_kernel;
 // mode 1: stem_wgrad's (feature vector f, thread) layout, dW in PyTorch's [64][3][7][7].
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(1024) void wgrad_fold_kernel(const f32x4_t* __restr
   __shared__ f32x4_t red[16][64];
   const int NT = 256 * kh_n, taps = ev >> 2;                        // threads per workgroup; ev = accumulator vectors per thread
   const size_t per_wg = (size_t)ev * NT;
-  const size_t v = (size_t)blockIdx.x * 64 + threadIdx.x;           // (by, bx, e, tid) flattened, tid fastest; the total is a multiple of 64
+  const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (by, bx, e, tid) flattened, tid fastest; the total is a multiple of 64
   const int ZG = blockDim.y, zl = threadIdx.y;
   const int tid = (int)(v % NT);
   const int e = (int)((v / NT) % ev);
@@ -373,7 +373,9 @@ static hipError_t fold_launch(const void* slabs, float* dw, int C, int gx, int g
   const size_t nvec = (size_t)gx * gy * ev * 256 * kh_n;
   int zg = 1;                                                       // >= 4 vectors per split lane, at most 16 lanes
   while (zg < 16 && splits >= 8 * zg) zg *= 2;
-  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)(nvec / 64)), dim3(64, zg), 0, st, reinterpret_cast<const f32x4_t*>(slabs), dw, C, gx, gy,
+  int vx = 64;                                                      // vectors per block: fewer where the launch would not fill the chip
+  while (vx > 16 && nvec / vx < (size_t)(2 * device_cus())) vx >>= 1;
+  hipLaunchKernelGGL(wgrad_fold_kernel, dim3((unsigned)(nvec / vx)), dim3(vx, zg), 0, st, reinterpret_cast<const f32x4_t*>(slabs), dw, C, gx, gy,
                      splits, ev, kh_n, mode);
   return hipGetLastError();
 }

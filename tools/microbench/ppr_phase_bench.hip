@@ -1,0 +1,65 @@
+// Where does a stage's time go in the ping-pong conv with the refilled filter bank (csrc/conv_ppr.hip)?
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSSLCR_PR_PROF tools/microbench/ppr_phase_bench.hip -o ppr_phase_bench
+//   ./ppr_phase_bench [N] [H=W] [C=K] [op: 0 plain + stats, 1 bias + residual + relu, 3 prologue + stats]
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../ssl_cr_histo_amd/csrc/conv_ppr.hip"
+namespace sslcr {
+int device_cus() { return 256; }
+}
+using namespace sslcr;
+
+int main(int argc, char** argv) {
+  const int N = argc > 1 ? atoi(argv[1]) : 640, H = argc > 2 ? atoi(argv[2]) : 32, C = argc > 3 ? atoi(argv[3]) : 128;
+  const int op = argc > 4 ? atoi(argv[4]) : 0;
+  const size_t elems = (size_t)N * H * H * C;
+  uint16_t *x, *y, *r, *w;
+  float *stats, *vec;
+  hipMalloc(&x, elems * 2); hipMalloc(&y, elems * 2); hipMalloc(&r, elems * 2); hipMalloc(&w, (size_t)C * 9 * C * 2);
+  hipMalloc(&stats, 256 * 4 * 2 * C * 4 * 2); hipMalloc(&vec, 4 * C * 4);
+  std::vector<uint16_t> hx(1 << 20);
+  for (size_t i = 0; i < hx.size(); ++i) hx[i] = (uint16_t)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));     // random bf16 around +-1
+  for (size_t o = 0; o < elems; o += hx.size()) {
+    const size_t n = elems - o < hx.size() ? elems - o : hx.size();
+    hipMemcpy(x + o, hx.data(), n * 2, hipMemcpyHostToDevice);
+    hipMemcpy(r + o, hx.data(), n * 2, hipMemcpyHostToDevice);
+  }
+  for (size_t o = 0; o < (size_t)C * 9 * C; o += hx.size()) {
+    const size_t n = (size_t)C * 9 * C - o < hx.size() ? (size_t)C * 9 * C - o : hx.size();
+    hipMemcpy(w + o, hx.data(), n * 2, hipMemcpyHostToDevice);
+  }
+  std::vector<float> hv(4 * C, 0.5f);
+  hipMemcpy(vec, hv.data(), 4 * C * 4, hipMemcpyHostToDevice);
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = w; a.y = y; a.N = N; a.H = H; a.W = H; a.C = C; a.K = C; a.R = 3; a.S = 3; a.stride = 1; a.pad = 1;
+  a.PH = H; a.PW = H; a.OH = H; a.OW = H; a.osh = 1;
+  if (op == 0) a.stats = stats;
+  if (op == 1) { a.residual = r; a.bias = vec; a.relu = 1; }
+  if (op == 3) { a.in_scale = vec; a.in_shift = vec + C; a.in_relu = 1; a.stats = stats; }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) launch_conv_ppr(a, 256, 0);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  const int reps = 10;
+  for (int i = 0; i < reps; ++i) launch_conv_ppr(a, 256, 0);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long prof[8][8];
+  hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_pr_prof), sizeof(prof));
+  const int nslab = C / 64;
+  const int tiles = N * (H / 16) * (H / 16), kbn = C / 64;
+  const double st = (double)(((tiles + 1) / 2 + (256 / kbn) - 1) / (256 / kbn)) * nslab;        // stages of a group of workgroup 0
+  printf("N=%d %dx%d C=K=%d op=%d: %.1f us/launch, %.1f TF/s (a stage = 288 MFMAs per wave = 4608 pipe cycles; two groups share a SIMD's pipe)\n", N, H, H, C, op,
+         ms * 1e3 / reps, 2.0 * elems * C * 9 / (ms / reps * 1e-3) / 1e12);
+  for (int wv = 0; wv < 8; wv += (wv == 0 ? 3 : (wv == 3 ? 1 : 3))) {
+    if (wv > 7) break;
+    printf("  wave %d (group %d): %4.0f stages, per stage: M %6.0f + barrier %6.0f | W %6.0f (halo transform %5.0f, output stage %5.0f per stage) + barrier %6.0f\n", wv, wv >> 2, st,
+           prof[wv][0] / st, prof[wv][1] / st, prof[wv][2] / st, prof[wv][4] / st, prof[wv][6] / st, prof[wv][3] / st);
+  }
+  return 0;
+}
