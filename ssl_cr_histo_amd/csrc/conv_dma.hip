@@ -245,15 +245,27 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
         s1[t * 4 + j] = x1;
         s2[t * 4 + j] = x2;
       }
+    float* sp = a.stats + ((size_t)(pb * WP + wp) * 2) * a.K + kb;
+    if constexpr (4 * TK == 16) {
+      // sixteen values over the 16 lanes of the DPP row in 32 instructions (row16_fold16, common.hpp): quad q of the row ends up with
+      // values 4q..4q+3 and stores that 16-byte piece
+      row16_fold16(s1);
+      row16_fold16(s2);
+      if ((li & 3) == 0) {
+        const int q4 = (li >> 2) * 4;
+        *reinterpret_cast<f32x4_t*>(sp + q4) = f32x4_t{s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<f32x4_t*>(sp + a.K + q4) = f32x4_t{s2[0], s2[1], s2[2], s2[3]};
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4 * TK; j += 4) {        // DPP folded into the adds: half the instructions of row16_sum()
-      row16_sum4(s1[j], s1[j + 1], s1[j + 2], s1[j + 3]);
-      row16_sum4(s2[j], s2[j + 1], s2[j + 2], s2[j + 3]);
-    }
-    if (li == 0) {
-      float* sp = a.stats + ((size_t)(pb * WP + wp) * 2) * a.K + kb;
+      for (int j = 0; j < 4 * TK; j += 4) {      // DPP folded into the adds: half the instructions of row16_sum()
+        row16_sum4(s1[j], s1[j + 1], s1[j + 2], s1[j + 3]);
+        row16_sum4(s2[j], s2[j + 1], s2[j + 2], s2[j + 3]);
+      }
+      if (li == 0) {
 #pragma unroll
-      for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
+        for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
+      }
     }
   }
 }

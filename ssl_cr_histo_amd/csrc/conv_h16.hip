@@ -73,8 +73,12 @@ __device__ unsigned long long g_h16_prof[16][8];
 //     15th step, so the next halo (and the residual) is requested at the TOP of the stage and has ~14 steps to land; with
 //     the ring, the short 8-MFMA steps of this shape left the HBM round trip of the halo half exposed and paid 8 barriers
 //     per 144 MFMAs.
-template <typename T, int BKO, int WK, bool XF, bool WR>
-__global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items, const int kshift,
+// RAW: the output stage of the train-mode forward -- no bias, no residual, no ReLU, no mask, statistics wanted (checked by the
+//     launcher): pack + store + the BatchNorm partial sums, as an instance of its own.  An output-stage instruction costs ~4 cycles
+//     (no MFMA runs beside it), so the 64 bias adds and 64 clamps of the general body are worth an instance; as run-time cases
+//     INSIDE one instance the duplicated bodies spilled (round 3).
+template <typename T, int BKO, int WK, bool XF, bool WR, bool RAW = false>
+__global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items, const int kshift,
                                                                   const int flags) {
   constexpr int NT = 256 * WK;
   constexpr int EPC = Elem<T>::EPC;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   // there is no bias -- they put a compiler vmcnt(0) in front of the output stores
   float* s_bias = s_stat + 8 * BKO;
   // BatchNorm-backward front end (sslcr_conv_desc.mask_x): s_bias holds the BatchNorm's scale, two more arrays its shift and mean
-  const bool mk = !XF && a.mask_x != nullptr;
+  const bool mk = !XF && !RAW && a.mask_x != nullptr;
   float* s_msh = s_bias + a.K;
   float* s_mmu = s_msh + a.K;
   for (int i = tid; i < a.K; i += NT) {
@@ -290,11 +294,11 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
   char* yg = reinterpret_cast<char*>(a.y);
   // no residual with an input transform (conv_h16_ok): a residual load in the epilogue -- even one skipped at run time --
   // made the compiler put a vmcnt(0) in front of every output store, i.e. eight serial write round trips per item
-  const char* rg = XF ? nullptr : reinterpret_cast<const char*>(a.mask_x ? a.mask_x : a.residual);   // same shape, same prefetch
+  const char* rg = (XF || RAW) ? nullptr : reinterpret_cast<const char*>(a.mask_x ? a.mask_x : a.residual);   // same shape, same prefetch
   // bf16 residual (teacher conv2 / the skip gradient of a block's first dgrad): requested with the next halo in the middle
   // of the item's LAST stage, so its HBM round trip sits under six steps of MFMAs instead of in front of the epilogue
   // (the epilogue-time load cost 57-80 us per layer1 launch, one exposed latency per tile)
-  constexpr bool RPRE = sizeof(T) == 2 && !XF;
+  constexpr bool RPRE = sizeof(T) == 2 && !XF && !RAW;
   constexpr int RQ = 4 * TK / EPC;
   u32x4_t rres[RPRE ? TP : 1][RPRE ? RQ : 1];
   auto out_off = [&](const Geo& q, int p) {
@@ -442,6 +446,19 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
           for (int e = 0; e < EPC; ++e) { s1[q * EPC + e] = a1[e]; s2[q * EPC + e] = a2[e]; }
         }
       } else {
+      if constexpr (RAW) {
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+          const size_t off = out_off(cur, p);
+#pragma unroll
+          for (int q = 0; q < 4 * TK / EPC; ++q) {
+            float vq[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) vq[e] = acc[(q * EPC + e) >> 2][p][(q * EPC + e) & 3];
+            st16(yg + off + q * 16, PackH<T>::run(vq));
+          }
+        }
+      } else {
       float bias[4 * TK];
 #pragma unroll
       for (int j = 0; j < 4 * TK; ++j) bias[j] = s_bias[kb + j];
@@ -469,6 +486,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
           st16(yg + off + q * 16, PackH<T>::run(vq));
         }
       }
+      }
       if (a.stats) {
 #pragma unroll
         for (int t = 0; t < TK; ++t)
@@ -483,23 +501,29 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_h16_kernel(const ConvArgs
       }
       }
       // s1 / s2: this lane's sums over its four pixel rows; now over the 16 pixel columns (the lanes of a DPP row)
-      constexpr bool FOLD = 4 * TK == 16;
+      constexpr bool FOLD = (4 * TK) % 16 == 0;
       if (a.stats) {
         if constexpr (FOLD) {
-          // quad q of the row ends up with the sums of kouts 4q..4q+3 in s[0..3] (row16_fold16: 32 DPP adds per 16 values where
-          // 16 row16_sum calls are 128 instructions as compiled); its first lane adds them into the workgroup's running sums
-          row16_fold16(s1);
-          row16_fold16(s2);
+          // per 16 values: quad q of the row ends up with the sums of kouts 4q..4q+3 in s[0..3] (row16_fold16: 32 DPP adds per 16
+          // values where 16 row16_sum calls are 128 instructions as compiled); its first lane adds them into the workgroup's sums
+#pragma unroll
+          for (int f = 0; f < 4 * TK / 16; ++f) {
+            row16_fold16(*reinterpret_cast<float (*)[16]>(s1 + 16 * f));
+            row16_fold16(*reinterpret_cast<float (*)[16]>(s2 + 16 * f));
+          }
           if ((li & 3) == 0) {
             float* sp = s_stat + (wp * 2) * BKO + wk * (BKO / WK) + g * (4 * TK) + (li >> 2) * 4;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-              const float* sv = h ? s2 : s1;
-              f32x4_t* slot = reinterpret_cast<f32x4_t*>(sp + h * BKO);
-              f32x4_t v = *slot;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += sv[e];
-              *slot = v;
+              for (int f = 0; f < 4 * TK / 16; ++f) {
+                const float* sv = (h ? s2 : s1) + 16 * f;
+                f32x4_t* slot = reinterpret_cast<f32x4_t*>(sp + h * BKO + 16 * f);
+                f32x4_t v = *slot;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += sv[e];
+                *slot = v;
+              }
             }
           }
         } else {
@@ -590,13 +614,18 @@ int conv_h16_rows(const ConvArgs& a) {
 
 // bf16 64 -> 64: one 128-byte slab of input channels and one kout block, the filter bank fits LDS whole
 static bool h16_resident(const ConvArgs& a) { return a.C == 64 && a.K == 64; }
+// the train-mode forward's output stage (the RAW instance); SSLCR_H16_RAW=0 keeps the general body for same-box A/B runs
+static bool h16_raw(const ConvArgs& a) {
+  static const bool on = [] { const char* e = getenv("SSLCR_H16_RAW"); return !e || atoi(e) != 0; }();
+  return on && a.stats && !a.bias && !a.relu && !a.residual && !a.mask_x;
+}
 
-template <typename T, int BKO, int WK, bool XF, bool WR = false>
+template <typename T, int BKO, int WK, bool XF, bool WR = false, bool RAW = false>
 static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
   const size_t lds = 18 * 24 * 128 + (WR ? 3 : 2) * 3 * BKO * 128 + 2 * a.C * sizeof(float) + 8 * BKO * sizeof(float) +
                      (a.mask_x ? 3 : 1) * a.K * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  auto kern = conv3x3_h16_kernel<T, BKO, WK, XF, WR>;
+  auto kern = conv3x3_h16_kernel<T, BKO, WK, XF, WR, RAW>;
   static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -617,12 +646,16 @@ static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
 template <typename T>
 static hipError_t launch_ht(const ConvArgs& a, hipStream_t st) {
   const bool xf = a.in_scale != nullptr;
-  if constexpr (sizeof(T) == 2) {
-    // ping-pong form with the refilled filter bank (conv_ppr.hip): the 128- / 256-channel shapes
-    const int hg = h16_grid(a, a.K % 128 == 0 ? 128 : 64);
-    if (conv_ppr_ok(DT_BF16, a, hg)) return launch_conv_ppr(a, hg, st);
+  if (a.K % 128 == 0) {
+    if constexpr (sizeof(T) == 2) {
+      // experiment (SSLCR_H16_W4=1): the same kernel as FOUR waves, one per SIMD with up to 512 registers, each 64 pixels x 128 kouts
+      static const bool w4 = [] { const char* e = getenv("SSLCR_H16_W4"); return e && atoi(e) != 0; }();
+      if (w4 && !xf) return h16_raw(a) ? launch_h<T, 128, 1, false, false, true>(a, st) : launch_h<T, 128, 1, false, false, false>(a, st);
+    }
+    if constexpr (sizeof(T) == 2)
+      if (h16_raw(a)) return xf ? launch_h<T, 128, 2, true, false, true>(a, st) : launch_h<T, 128, 2, false, false, true>(a, st);
+    return xf ? launch_h<T, 128, 2, true>(a, st) : launch_h<T, 128, 2, false>(a, st);
   }
-  if (a.K % 128 == 0) return xf ? launch_h<T, 128, 2, true>(a, st) : launch_h<T, 128, 2, false>(a, st);
   if constexpr (sizeof(T) == 2)
     if (h16_resident(a)) {
       if (conv_pp64_ok(DT_BF16, a)) return launch_conv_pp64(a, st);        // ping-pong form (conv_pp64.hip)
@@ -638,16 +671,17 @@ hipError_t launch_conv_h16(int dtype, const ConvArgs& a, hipStream_t st) {
 
 const char* conv_h16_name(int dtype, const ConvArgs& a) {
   const bool bf = dtype == DT_BF16, xf = a.in_scale != nullptr;
-  if (bf && conv_ppr_ok(DT_BF16, a, h16_grid(a, a.K % 128 == 0 ? 128 : 64))) return conv_ppr_name(a);
   if (a.K % 128 == 0) {
-    if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, true, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, false, false>";
-    return xf ? "sslcr::conv3x3_h16_kernel<float, 128, 2, true, false>" : "sslcr::conv3x3_h16_kernel<float, 128, 2, false, false>";
+    if (bf && h16_raw(a))
+      return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, true, false, true>" : "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, false, false, true>";
+    if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, true, false, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 128, 2, false, false, false>";
+    return xf ? "sslcr::conv3x3_h16_kernel<float, 128, 2, true, false, false>" : "sslcr::conv3x3_h16_kernel<float, 128, 2, false, false, false>";
   }
   if (bf && h16_resident(a) && conv_pp64_ok(DT_BF16, a)) return conv_pp64_name(a);
   if (bf && h16_resident(a))
-    return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true, true>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false, true>";
-  if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false, false>";
-  return xf ? "sslcr::conv3x3_h16_kernel<float, 64, 2, true, false>" : "sslcr::conv3x3_h16_kernel<float, 64, 2, false, false>";
+    return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true, true, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false, true, false>";
+  if (bf) return xf ? "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, true, false, false>" : "sslcr::conv3x3_h16_kernel<unsigned short, 64, 2, false, false, false>";
+  return xf ? "sslcr::conv3x3_h16_kernel<float, 64, 2, true, false, false>" : "sslcr::conv3x3_h16_kernel<float, 64, 2, false, false, false>";
 }
 
 }  // namespace sslcr

@@ -300,13 +300,27 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
         float x1 = 0.f, x2 = 0.f;
 #pragma unroll
         for (int p = 0; p < TP; ++p) { float q = acc[t][p][j]; x1 += q; x2 = fmaf(q, q, x2); }
-        s1[t * 4 + j] = row16_sum(x1);
-        s2[t * 4 + j] = row16_sum(x2);
+        s1[t * 4 + j] = x1;
+        s2[t * 4 + j] = x2;
       }
-    if (li == 0) {
-      float* sp = a.stats + ((size_t)((blockIdx.x + tile0) * 4 + wp) * 2) * a.K + kb;
+    float* sp = a.stats + ((size_t)((blockIdx.x + tile0) * 4 + wp) * 2) * a.K + kb;
+    if constexpr (4 * TK == 16) {
+      // sums over the 16 lanes of the DPP row, sixteen values at a time (common.hpp: 32 DPP adds per set where 16 row16_sum calls are
+      // 128 instructions as compiled): quad q of the row ends up with values 4q..4q+3 and stores that 16-byte piece
+      row16_fold16(s1);
+      row16_fold16(s2);
+      if ((li & 3) == 0) {
+        const int q4 = (li >> 2) * 4;
+        *reinterpret_cast<f32x4_t*>(sp + q4) = f32x4_t{s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<f32x4_t*>(sp + a.K + q4) = f32x4_t{s2[0], s2[1], s2[2], s2[3]};
+      }
+    } else {
 #pragma unroll
-      for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
+      for (int j = 0; j < 4 * TK; ++j) { s1[j] = row16_sum(s1[j]); s2[j] = row16_sum(s2[j]); }
+      if (li == 0) {
+#pragma unroll
+        for (int j = 0; j < 4 * TK; ++j) { sp[j] = s1[j]; sp[a.K + j] = s2[j]; }
+      }
     }
   }
 }

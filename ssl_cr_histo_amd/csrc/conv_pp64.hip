@@ -325,11 +325,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
             if (live) st16(yg + out_off(cur, p) + q * 64, PackH<T>::run(vq));      // (uniform)
           }
 #pragma unroll
-          for (int e = 0; e < EPC; e += 4) {
-            row16_sum4(a1[e], a1[e + 1], a1[e + 2], a1[e + 3]);
-            row16_sum4(a2[e], a2[e + 1], a2[e + 2], a2[e + 3]);
-          }
-#pragma unroll
           for (int e = 0; e < EPC; ++e) { s1[q * EPC + e] = a1[e]; s2[q * EPC + e] = a2[e]; }
         }
       } else {
@@ -379,26 +374,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
               s1[t * 4 + j] = x1;
               s2[t * 4 + j] = x2;
             }
-#pragma unroll
-          for (int j = 0; j < 4 * TK; j += 4) {
-            row16_sum4(s1[j], s1[j + 1], s1[j + 2], s1[j + 3]);
-            row16_sum4(s2[j], s2[j + 1], s2[j + 2], s2[j + 3]);
-          }
         }
       }
-      if (a.stats && live && li == 0) {
-        // every (wave row, kout) entry has exactly ONE writer lane in the whole workgroup, so the running sums are updated with
-        // plain 16-byte reads and writes: 32 LDS float atomics per tile cost ~1400 cycles (each holds the LDS pipe ~40), this ~250
-        float* sp = s_stat + (wq * 2) * BKO + kb;
+      if (a.stats) {
+        // s1 / s2: this lane's sums over its four pixel rows; now over the 16 pixel columns (the lanes of a DPP row).  row16_fold16
+        // (32 DPP adds per 16 values; row16_sum4 took 64) leaves quad q of the row with values 4q..4q+3 in s[0..3]: value idx = t * 4 + j
+        // is channel kb + (t >> 1) * 32 + (t & 1) * 4 + j, so quad q = t owns one 16-byte piece of the running sums.  Every
+        // (wave row, kout) entry has exactly ONE writer lane in the whole workgroup: plain 16-byte reads and writes, a fixed order
+        // (32 LDS float atomics per tile cost ~1400 cycles, each holds the LDS pipe ~40)
+        row16_fold16(s1);
+        row16_fold16(s2);
+        if (live && (li & 3) == 0) {
+          const int t = li >> 2;
+          float* sp = s_stat + (wq * 2) * BKO + kb + (t >> 1) * 32 + (t & 1) * 4;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                      // h = 0: sums, 1: sums of squares (or of g * (x - mean))
-          const float* sv = h ? s2 : s1;
-#pragma unroll
-          for (int c4 = 0; c4 < 4; ++c4) {                 // four 16-byte pieces: channels kb + (c4 >> 1) * 32 + (c4 & 1) * 4 + 0..3
-            f32x4_t* slot = reinterpret_cast<f32x4_t*>(sp + h * BKO + (c4 >> 1) * 32 + (c4 & 1) * 4);
+          for (int h = 0; h < 2; ++h) {                    // h = 0: sums, 1: sums of squares (or of g * (x - mean))
+            const float* sv = h ? s2 : s1;
+            f32x4_t* slot = reinterpret_cast<f32x4_t*>(sp + h * BKO);
             f32x4_t v = *slot;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += sv[c4 * 4 + e];
+            for (int e = 0; e < 4; ++e) v[e] += sv[e];
             *slot = v;
           }
         }

@@ -48,11 +48,6 @@ bool conv_pp64_ok(int dtype, const ConvArgs& a);
 hipError_t launch_conv_pp64(const ConvArgs& a, hipStream_t st);
 const char* conv_pp64_name(const ConvArgs& a);
 int conv_pp64_rows(const ConvArgs& a);
-// conv_ppr.hip: ping-pong form with a refilled 64 x 64 filter bank for the bf16 128- / 256-channel shapes (h16_grid: the workgroup
-// count conv3x3_h16 would use -- it sizes the caller's statistics rows)
-bool conv_ppr_ok(int dtype, const ConvArgs& a, int h16_grid);
-hipError_t launch_conv_ppr(const ConvArgs& a, int h16_grid, hipStream_t st);
-const char* conv_ppr_name(const ConvArgs& a);
 // conv_dma.hip
 int conv_dma_bp(int dtype, const ConvArgs& a);
 int conv_dma_rows(const ConvArgs& a, int bp);

@@ -95,8 +95,6 @@ def test_conv_fwd_raw_stats(case, dtype):
     expect = {(33, 32, 32, 64, 256, 3, 1, 1): "conv3x3_h16_kernel", (10, 30, 34, 64, 128, 3, 2, 1): "conv_dma_kernel",
               (10, 30, 34, 128, 64, 3, 2, 1): "conv_dma_kernel", (9, 32, 32, 64, 128, 1, 2, 0): "conv_dma_kernel",
               (4, 8, 8, 512, 512, 3, 1, 1): "conv3x3_halo256_kernel"}.get(case)
-    if expect == "conv3x3_h16_kernel" and dtype == 1:
-        expect = "conv3x3_ppr_kernel"              # bf16: the ping-pong form with the refilled bank serves this shape (conv_ppr.hip)
     if expect:
         assert expect in K.last_conv_kernel, K.last_conv_kernel
     if case == (70, 32, 32, 64, 64, 3, 1, 1) and dtype == 1:      # 280 tiles on 256 workgroups: the resident-filter walk
@@ -273,8 +271,7 @@ def test_conv_bn_backward_front_end(case, dtype):
     sc, sh, mu = rnd(84, (Ko,)), rnd(85, (Ko,)), rnd(86, (Ko,))
     y, stats = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, want_stats=True,
                         mask=(to_dev(xbn, dtype), sc.to(DEV), sh.to(DEV), mu.to(DEV)))
-    want_kernel = "conv3x3_h16_kernel" if dtype == 0 else ("conv3x3_pp64_kernel<false, 2>" if (C == 64 and Ko == 64) else "conv3x3_ppr_kernel<false, 2>")
-    assert want_kernel in K.last_conv_kernel, K.last_conv_kernel
+    assert ("conv3x3_pp64_kernel<false, 2>" if (C == 64 and Ko == 64 and dtype == 1) else "conv3x3_h16_kernel") in K.last_conv_kernel, K.last_conv_kernel
     want = R.conv_fwd(x, w, 1, 1)
     keep = (xbn * sc + sh) > 0
     g = want * keep
@@ -809,59 +806,6 @@ def test_conv_pingpong_64(case, op):
     else:
         y = out
     close(y, want, TOL[dtype], f"pp64 {op}")
-
-
-@pytest.mark.parametrize("case", [(1, 16, 16, 128, 128), (1, 16, 32, 128, 128), (3, 16, 16, 128, 128), (5, 48, 32, 128, 128), (33, 32, 32, 128, 128),
-                                  (160, 32, 32, 128, 128), (2, 16, 16, 256, 256), (70, 16, 16, 256, 256), (300, 16, 16, 256, 256),
-                                  (5, 32, 32, 64, 128), (3, 16, 16, 128, 256), (9, 16, 16, 256, 128)])
-@pytest.mark.parametrize("op", ["plain_stats", "residual_relu_bias", "prologue_stats", "mask"])
-def test_conv_pingpong_refilled_bank(case, op):
-    """conv_ppr.hip, the ping-pong form with the refilled 64 x 64 filter bank (bf16 3x3 convs of layers 2-3: forward, eval-fused
-    forward, both dgrads): every operand combination it serves, on walks that exercise the refill schedule -- one tile (group 1 never
-    live), two, odd tile counts, fewer items than workgroups, more than one round per workgroup (160 x 4 tiles x 2 kout blocks = 640
-    items on 256 workgroups; 300 tiles x 4 blocks), one to four slabs per tile, one / two / four kout blocks (the workgroup's block is
-    fixed; the other blocks' statistics columns of its rows must be zero), C != K."""
-    K = _k()
-    N, H, W, C, Ko = case
-    dtype = 1
-    x = q(rnd(191, (N, H, W, C)), dtype)
-    w = q(rnd(192, (Ko, 3, 3, C), 0.05), dtype)
-    kw, ref_kw = {}, {}
-    if op == "residual_relu_bias":
-        res, bias = q(rnd(193, (N, H, W, Ko)), dtype), rnd(194, (Ko,))
-        kw = dict(residual=to_dev(res, dtype), bias=bias.to(DEV), relu=True)
-        ref_kw = dict(residual=res, bias=bias, relu=True)
-    if op == "prologue_stats":
-        sc, sh = rnd(195, (C,)).abs() + 0.5, rnd(196, (C,))
-        kw = dict(in_scale=sc.to(DEV), in_shift=sh.to(DEV), in_relu=True, want_stats=True)
-        ref_kw = dict(in_scale=sc, in_shift=sh, in_relu=True)
-    if op == "plain_stats":
-        kw = dict(want_stats=True)
-    if op == "mask":
-        xbn = q(rnd(197, (N, H, W, Ko), 2.0) + 0.3, dtype)
-        sc, sh, mu = rnd(198, (Ko,)), rnd(199, (Ko,)), rnd(200, (Ko,))
-        y, stats = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, want_stats=True, mask=(to_dev(xbn, dtype), sc.to(DEV), sh.to(DEV), mu.to(DEV)))
-        assert "conv3x3_ppr_kernel<false, 2>" in K.last_conv_kernel, K.last_conv_kernel
-        want = R.conv_fwd(x, w, 1, 1)
-        g = want * ((xbn * sc + sh) > 0)
-        edge = (xbn * sc + sh).abs() < 1e-6
-        close(torch.where(edge.to(DEV), torch.zeros_like(y), y), torch.where(edge, torch.zeros_like(g), g), TOL[dtype], "masked dgrad")
-        st = stats.double().sum(0).cpu()
-        close(st[0], g.double().sum((0, 1, 2)), 3e-3, "sum g")
-        close(st[1], (g.double() * (xbn.double() - mu.double())).sum((0, 1, 2)), 3e-3, "sum g (x - mean)")
-        return
-    out = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, **kw)
-    assert "conv3x3_ppr_kernel" in K.last_conv_kernel, K.last_conv_kernel
-    want = R.conv_fwd(x, w, 1, 1, **ref_kw)
-    if kw.get("want_stats"):
-        y, stats = out
-        s, ss = R.channel_stats(want)
-        st = stats.double().sum(0).cpu()
-        close(st[0], s, 2e-3, "sum")
-        close(st[1], ss, 2e-3, "sumsq")
-    else:
-        y = out
-    close(y, want, TOL[dtype], f"ppr {op}")
 
 
 @pytest.mark.parametrize("in_u8", [True, False])
