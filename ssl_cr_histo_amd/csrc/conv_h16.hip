@@ -78,8 +78,7 @@ __device__ unsigned long long g_h16_prof[16][8];
 //     (no MFMA runs beside it), so the 64 bias adds and 64 clamps of the general body are worth an instance; as run-time cases
 //     INSIDE one instance the duplicated bodies spilled (round 3).
 template <typename T, int BKO, int WK, bool XF, bool WR, bool RAW = false>
-__global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items, const int kshift,
-                                                                  const int flags) {
+__global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(const ConvArgs a, const int tiles_total, const int n_items, const int kshift) {
   constexpr int NT = 256 * WK;
   constexpr int EPC = Elem<T>::EPC;
   constexpr int CE = 8 * EPC;                 // channels per 128-byte slab
@@ -306,9 +305,7 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
     return ((((size_t)q.n0 * a.H + h) * a.W + w) * a.K + q.k0 + wk * (BKO / WK) + g * (4 * TK)) * sizeof(T);
   };
   int wb = 0, item = first, slab = 0;
-  // static priority for the second-dispatched half of the workgroup (flags bit 0): the two waves of a SIMD are arbitrated by
-  // priority, then age, and waves 4-7 lose every contended issue slot to waves 0-3 (MI355X_MICROARCH.md, "Two waves per SIMD")
-  if ((flags & 1) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+  // (a static s_setprio 1 for waves 4-7 -- the arbitration losers of every contended issue slot -- measured 0.00 ms on the step, r04)
 #ifdef SSLCR_H16_PROF
   unsigned long long h16_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long h16_begin = __builtin_readcyclecounter();
@@ -638,8 +635,7 @@ static hipError_t launch_h(const ConvArgs& a, hipStream_t st) {
   const int grid = h16_grid(a, BKO);                                    // one 8-wave workgroup per CU
   const int kbn = a.K / BKO, gseg = grid / nseg;
   const int kshift = (kbn > 1 && (kbn & (kbn - 1)) == 0 && (gseg & (kbn - 1)) == 0) ? __builtin_ctz(kbn) : -1;
-  static const int flags = [] { const char* e = getenv("SSLCR_H16_PRIO"); return e ? atoi(e) : 0; }();
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WK), lds, st, a, tiles, n_items, kshift, flags);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WK), lds, st, a, tiles, n_items, kshift);
   return hipGetLastError();
 }
 
@@ -647,11 +643,6 @@ template <typename T>
 static hipError_t launch_ht(const ConvArgs& a, hipStream_t st) {
   const bool xf = a.in_scale != nullptr;
   if (a.K % 128 == 0) {
-    if constexpr (sizeof(T) == 2) {
-      // experiment (SSLCR_H16_W4=1): the same kernel as FOUR waves, one per SIMD with up to 512 registers, each 64 pixels x 128 kouts
-      static const bool w4 = [] { const char* e = getenv("SSLCR_H16_W4"); return e && atoi(e) != 0; }();
-      if (w4 && !xf) return h16_raw(a) ? launch_h<T, 128, 1, false, false, true>(a, st) : launch_h<T, 128, 1, false, false, false>(a, st);
-    }
     if constexpr (sizeof(T) == 2)
       if (h16_raw(a)) return xf ? launch_h<T, 128, 2, true, false, true>(a, st) : launch_h<T, 128, 2, false, false, true>(a, st);
     return xf ? launch_h<T, 128, 2, true>(a, st) : launch_h<T, 128, 2, false>(a, st);
