@@ -8,6 +8,6 @@ cd /root/repo
 python ssl_cr_histo_amd/build.py > /dev/null
 others=$(ls ssl_cr_histo_amd/build/*.o | grep -v "/$src.o")
 for m in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-result -D$m -x hip -c ssl_cr_histo_amd/csrc/$src.hip -o /tmp/abl_$m.o &&
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -D$m -x hip -c ssl_cr_histo_amd/csrc/$src.hip -o /tmp/abl_$m.o &&
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o exp/lib_$m.so /tmp/abl_$m.o $others -L/opt/rocm/lib -lrccl && echo built exp/lib_$m.so
 done

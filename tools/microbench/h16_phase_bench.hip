@@ -1,5 +1,5 @@
 // Where does a stage's time go in the persistent 16x16-tile conv (csrc/conv_h16.hip, the step's dominant kernel)?
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -DSSLCR_H16_PROF tools/microbench/h16_phase_bench.hip -o h16_phase_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSSLCR_H16_PROF tools/microbench/h16_phase_bench.hip -o h16_phase_bench
 //   ./h16_phase_bench [N] [H=W] [C=K] [op: 0 plain + stats, 1 bias + residual + relu, 3 prologue + stats]
 #include <cstdio>
 #include <cstring>

@@ -1,6 +1,6 @@
 // Where does a tile's time go in the ping-pong layer1 conv (csrc/conv_pp64.hip)?  Per wave of workgroup 0: shader cycles in the M
 // phase, at the barrier behind it, in the W phase, at the barrier behind that.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -DSSLCR_PP_PROF tools/microbench/pp64_phase_bench.hip -o pp64_phase_bench
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSSLCR_PP_PROF tools/microbench/pp64_phase_bench.hip -o pp64_phase_bench
 #include "../../ssl_cr_histo_amd/csrc/conv_pp64.hip"
 #include <cstdio>
 #include <cstring>
