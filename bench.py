@@ -12,7 +12,8 @@ teacher images = 1088 distinct patches), full fine-tune (--modules_student 0), M
 student train-mode forward, losses, full backward, gradient all-reduce (N>1), fused Adam update.  Weak scaling: the
 per-GPU batch is fixed.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0; at N=1 the line
 also carries the other BASELINE.json configurations measured in the same process (`also`: forward-only = config 2, RSP = config 3,
-the reference-default frozen backbone, and the fp32 exact-parity mode) and the CPU baseline of BASELINE.md section 3.
+the reference-default frozen backbone, and the fp32 exact-parity mode, config 5's shape in bf16 and fp8) and the CPU baseline of BASELINE.md section 3 (run alone, after the GPU
+legs of record).
 """
 import argparse
 import json
@@ -35,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 F_FWD = 2 * 2368733184            # backbone forward FLOPs per 256x256 image
 F_BWD_FULL = 2 * F_FWD - 0.308e9  # + dgrad + wgrad, no dgrad for conv1
-PMC_FILE = os.path.join("profiles", "r03_final_pmc_step.json")     # fallback only (tools/pmc_step.sh on the builder's lease): the line's
+PMC_FILE = os.path.join("profiles", "r04_a_pmc_step.json")     # fallback only (tools/pmc_step.sh on the builder's lease): the line's
                                                               # counters are measured IN this run by pmc_in_run() when rocprofv3 is there
 
 
