@@ -20,6 +20,7 @@ from unittest import mock
 
 import numpy as np
 import torch
+import torch.nn.functional as F_
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -662,6 +663,103 @@ def gen_traj_yard(name, out):
               f"state {out[f'{name}/state_err_t{th}'].max():.3e}")
 
 
+def gen_flip_yard(name, out):
+    """Yardstick for ONE thing the fp32 gradient bounds of the full-size cases cannot absorb: a head ReLU whose sign fp32 cannot
+    resolve.  fc.0 (models/net.py:35, Linear(1024, 512) + ReLU) sees 2e5 - 3e5 (sample, unit) pre-activations per iteration; the
+    smallest of them sits ~1e-6 from zero at an rms of 0.5 (rsp_full: pair 0, sample 54, unit 384: z = -1.08e-6 in float64), i.e.
+    inside the 1e-6 relative error of ANY fp32 forward.  Whether that unit's mask is 0 or 1 in an fp32 run is a coin flip that
+    changes with every summation order -- and because the unit fans out to the whole backbone, the flip moves every parameter's
+    gradient by 1-2e-2 of its norm (measured on the MI355X between two builds that differ in the lane order of a BatchNorm sum).
+    Stored, from the float64 run of the iteration (oracle restatement): the fragile units (|z| < 1e-5 x rms(z), at most four) and,
+    per parameter i, flip_l2[i] = sum_k ||D_k,i|| / ||g64_i|| and flip_pr[i] = sum_k |probe(D_k,i)| / ||g64_i||, where D_k is the
+    gradient that flows through fragile unit k alone (backward is linear in the upstream gradient, so the masks' contributions
+    add).  The GPU test widens its fp32 bounds by exactly these amounts and by nothing else."""
+    from collections import OrderedDict
+    from oracle import bf16_emul as B
+    base = name[:-5]
+    c = C.CASES[base]
+    hw = c["hw"]
+    g = np.load(os.path.join(HERE, f"{base}.npz"))
+    ident = lambda t: t                                                                  # noqa: E731
+    rsp = base == "rsp_full"
+    if rsp:
+        p, _ = _oracle_params("mlp", 6, torch.float64, False)
+        (i1, i2, i3, t), = C.rsp_batches(base)
+        es = [B.backbone_train(p, i.double(), ident) for i in (i1, i2, i3)]
+        cats = [torch.cat((es[a], es[b]), 1) for a, b in ((0, 1), (1, 2), (0, 2))]
+    else:
+        cls = {"bpq_cr_full": 1, "cam_cr_full": 2, "kather_sup_full": 9}[base]
+        p, b64 = _oracle_params("finetune", cls, torch.float64, True)
+        if base == "bpq_cr_full":
+            (xl, yl), = C.labeled_batches(base)
+            (uw, us), = C.unlabeled_batches(base)
+            x, y, u_s, u_w = xl.reshape(-1, 3, hw, hw), yl.reshape(-1).double(), us, uw
+        elif base == "cam_cr_full":
+            (tx, ty), = C.labeled_batches_cls(base, 1000, 1)
+            (nx_, ny), = C.labeled_batches_cls(base, 1100, 0)
+            (tuw, tus), = C.unlabeled_batches(base, 2000)
+            (nuw, nus), = C.unlabeled_batches(base, 2100)
+            tx, nx_ = tx.reshape(-1, 3, hw, hw), nx_.reshape(-1, 3, hw, hw)
+            torch.manual_seed(777)
+            p_x, p_uw, p_us = torch.randperm(2 * len(tx)), torch.randperm(2 * len(tuw)), torch.randperm(2 * len(tus))
+            x, y = torch.cat([tx, nx_])[p_x], torch.cat([ty.reshape(-1), ny.reshape(-1)])[p_x]
+            u_w, u_s = torch.cat([tuw, nuw])[p_uw], torch.cat([tus, nus])[p_us]
+        else:
+            raise KeyError(base)
+        with torch.no_grad():
+            pd = OrderedDict((k, v.detach()) for k, v in p.items())
+            lt = torch.cat([OM.classifier_forward(pd, OM.finetune_forward(pd, b64, u_w[i:i + 64].double(), False, True))
+                            for i in range(0, u_w.shape[0], 64)])
+        e = B.backbone_train(p, torch.cat((x, u_s)).double(), ident)
+        cats = [torch.cat((e, e), 1)]
+    zs, hs, fs = [], [], []
+    for cat in cats:
+        z = F_.linear(cat, p["fc.0.weight"], p["fc.0.bias"])
+        h = F_.relu(z)
+        h.retain_grad()
+        zs.append(z); hs.append(h)
+        fs.append(F_.linear(h, p["fc.2.weight"], p["fc.2.bias"]))
+    if rsp:
+        logits = OM.classifier_forward(p, torch.cat(fs, 1))
+        loss = F_.cross_entropy(logits, t.long().reshape(-1))
+    else:
+        logits = OM.classifier_forward(p, torch.cat((fs[0], fs[0], fs[0]), 1))
+        nx = x.shape[0]
+        if base == "bpq_cr_full":
+            loss = F_.mse_loss(logits[:nx], y.view(-1, 1)) + c["lambda_u"] * F_.mse_loss(lt, logits[nx:])
+        else:
+            loss = F_.cross_entropy(logits[:nx], y) + c["lambda_u"] * F_.cross_entropy(logits[nx:], torch.softmax(lt, -1).max(-1)[1])
+    names = [str(n) for n in g[f"{base}/grad_names"]]
+    params = [p[k] for k in names]
+    g64 = torch.autograd.grad(loss, params, retain_graph=True)
+    l2 = np.array([float(q.norm()) for q in g64])
+    assert np.allclose(l2, g[f"{base}/grad_l2_f64"], rtol=1e-9), "this float64 run is not the golden's float64 run"
+    hgrads = torch.autograd.grad(loss, hs, retain_graph=True)
+    flip_l2, flip_pr, units = np.zeros(len(names)), np.zeros(len(names)), []
+    for pi, (z, hg) in enumerate(zip(zs, hgrads)):
+        rms = float(z.detach().pow(2).mean().sqrt())
+        az = z.detach().abs().reshape(-1)
+        v, idx = az.sort()
+        for k in range(4):
+            if float(v[k]) >= 1e-5 * rms:
+                break
+            s_, u_ = int(idx[k]) // z.shape[1], int(idx[k]) % z.shape[1]
+            units.append((pi, s_, u_, float(z[s_, u_]), rms))
+            d = torch.autograd.grad(z[s_, u_], params, retain_graph=True, allow_unused=True)
+            up = float(hg[s_, u_])
+            for i, q in enumerate(d):
+                if q is None:
+                    continue
+                q = (q * up).reshape(-1)
+                flip_l2[i] += float(q.norm()) / (l2[i] + 1e-300)
+                flip_pr[i] += abs(float((q * C.grad_probe(i, q.numel())).sum())) / (l2[i] + 1e-300)
+    out[f"{name}/ret"] = np.array([float(loss.detach())])
+    out[f"{name}/units"] = np.array(units, dtype=np.float64).reshape(-1, 5)     # (pair, sample, unit, z, rms(z)) per fragile unit
+    out[f"{name}/flip_l2"] = flip_l2
+    out[f"{name}/flip_pr"] = flip_pr
+    print(f"  {name}: fragile units {units}; max flip_l2 {flip_l2.max():.3e}, max flip_pr {flip_pr.max():.3e}")
+
+
 # ---------------------------------------------------------------- checkpoint layouts (row f2)
 def tree_struct(obj, path=""):
     """JSON-able description of a checkpoint: containers with their types and key order, tensors as (dtype, shape, path),
@@ -941,6 +1039,7 @@ def main():
             "cam_wsi": gen_cam_wsi, "cam_wsi_large": gen_cam_wsi, "bpq_cr_full": gen_bpq_cr_full, "rsp_full": gen_rsp_full, "cam_cr_full": gen_cam_cr_full,
             "kather_sup": gen_kather_sup, "kather_sup_full": gen_kather_sup_full, "traj_bpq_cr": gen_traj, "traj_cam_cr": gen_traj,
             "traj_bpq_cr_yard": gen_traj_yard, "traj_cam_cr_yard": gen_traj_yard,
+            "rsp_full_flip": gen_flip_yard, "bpq_cr_full_flip": gen_flip_yard, "cam_cr_full_flip": gen_flip_yard,
             "ckpt_bpq_cr": gen_ckpt_bpq_cr, "ckpt_cam_sup": gen_ckpt_cam_sup, "ckpt_rsp": gen_ckpt_rsp}
     only = sys.argv[1:]
     for name, fn in gens.items():

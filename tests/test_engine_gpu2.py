@@ -450,7 +450,8 @@ def test_virtual_ranks_equal_the_single_device_step(world, workload, dtype):
         assert torch.allclose(total[:3], single["losses"][:3], rtol=tl, atol=1e-7), (total, single["losses"])
     else:
         held(f"vranks/{workload}/w{world}/losses/{dtype}", float(((total[:3] - single["losses"][:3]).abs() / (single["losses"][:3].abs() + 1e-7)).max()),
-             tl, floor=1e-3)
+             tl, floor=5e-3)      # (bf16: the W-rank run and the 1-rank run round differently ordered sums into bf16 activations; the
+                                  #  difference moved 5e-4 ... 4.2e-3 over this project's changes of summation order)
     assert abs(float(total[3] - single["losses"][3])) <= (0 if dtype == "fp32" else 2)           # correct-prediction counts add up
     worst = worst_state = 0.0
     prof = [float((a - b).norm() / (b.norm() + 1e-30)) for a, b in zip(ranks[0]["grads"], single["grads"])]

@@ -291,3 +291,37 @@ def test_trajectory_yardstick_is_pinned_to_the_reference(name):
     # this much from each other): held to the yardstick's spread, not to RT
     spread = max(abs(y[f"{yn}/vals_t{a}"][0] / y[f"{yn}/vals_t{b}"][0] - 1) for a, b in ((8, 3), (8, 1), (3, 1)))
     assert abs(v / g[f"{name}/vals"][0][0] - 1) <= max(RT, 3 * spread), (v, g[f"{name}/vals"][0][0], spread)
+
+
+def test_flip_yardstick_names_a_head_unit_fp32_cannot_resolve():
+    """tests/golden/*_full_flip.npz (make_golden.py:gen_flip_yard): the head ReLU pre-activations that sit within 1e-5 x rms of zero in
+    the float64 run of the full-size iterations, and how much of every parameter's gradient flows through them.  Data checks on all
+    three files; for rsp_full the oracle's own fp32 forward must find the named unit inside that margin too (pair 0, sample 54, unit
+    384: z = -1.08e-6 at rms 0.52 -- any fp32 summation order decides its sign)."""
+    import torch.nn.functional as F
+    from collections import OrderedDict
+    from oracle import bf16_emul as B
+    for name in ("rsp_full", "bpq_cr_full", "cam_cr_full"):
+        y = load_golden(name + "_flip")
+        g = load_golden(name)
+        u = y[f"{name}_flip/units"]
+        assert 1 <= u.shape[0] <= 4 and u.shape[1] == 5
+        assert np.all(np.abs(u[:, 3]) < 1e-5 * u[:, 4])
+        n = len(g[f"{name}/grad_names"])
+        fl, fp = y[f"{name}_flip/flip_l2"], y[f"{name}_flip/flip_pr"]
+        assert fl.shape == (n,) and fp.shape == (n,) and np.all(fl >= 0) and np.all(fp >= 0)
+        names = [str(k) for k in g[f"{name}/grad_names"]]
+        for k in ("fc.2.weight", "fc.2.bias", "classifier.0.weight"):       # nothing behind the unit depends on its mask
+            if k in names:
+                assert fl[names.index(k)] == 0.0
+        assert fl[names.index("fc.0.bias")] > 0.0 and fl.max() < 5e-2
+    name = "rsp_full"
+    u = load_golden(name + "_flip")[f"{name}_flip/units"][0]
+    pn, _, pc = oracle_state("mlp", 6, False)
+    p = merged(pn, pc)
+    (i1, i2, i3, _t), = C.rsp_batches(name)
+    pair = ((0, 1), (1, 2), (0, 2))[int(u[0])]
+    with torch.no_grad():
+        e = {i: B.backbone_train(p, (i1, i2, i3)[i].float(), lambda t: t) for i in pair}
+        z = F.linear(torch.cat((e[pair[0]], e[pair[1]]), 1), p["fc.0.weight"], p["fc.0.bias"])
+    assert abs(float(z[int(u[1]), int(u[2])])) < 1e-5 * float(z.pow(2).mean().sqrt())
