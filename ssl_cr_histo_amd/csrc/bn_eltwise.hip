@@ -811,7 +811,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_sums_kernel(const double* __restr
   const double* p = rows + ((size_t)blockIdx.y * nrows) * C2 + v;
   double s = 0.0;
   if (ok) {
-#pragma unroll 8
+#pragma unroll 16
     for (int r = yl; r < nrows; r += 16) s += __builtin_nontemporal_load(p + (size_t)r * C2);     // (loads independent: all in flight at once)
   }
   red[yl][threadIdx.x] = s;
