@@ -841,7 +841,7 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
     if (b4 > 256) b4 = 256;
   }
   const int nrows = (int)(big ? b4 : blocks);
-  double* rows = reinterpret_cast<double*>(wgrad_slabs(st, (size_t)nseg * nrows * 2 * a.C * sizeof(double)));
+  double* rows = reinterpret_cast<double*>(stream_scratch(st, (size_t)nseg * nrows * 2 * a.C * sizeof(double)));
   if (!rows) return hipErrorOutOfMemory;
   auto fold = [&]() {
     hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(2 * a.C, 64), nseg), dim3(64, 16), 0, st, rows, nrows, 2 * a.C, a.sums, nseg > 1 ? a.sums_stride : 0);

@@ -254,7 +254,7 @@ static hipError_t launch_w(const WgradArgs& a, hipStream_t st) {
   if (TAPS != a.R * a.S) return hipErrorInvalidValue;
   f32x4_t* slabs = nullptr;                      // accumulator slabs + the ordered fold whenever there is more than one pixel split
   if (splits > 1) {
-    slabs = reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * TAPS * 4 * 256 * KH * sizeof(f32x4_t)));
+    slabs = reinterpret_cast<f32x4_t*>(stream_scratch(st, (size_t)gx * gy * splits * TAPS * 4 * 256 * KH * sizeof(f32x4_t)));
     if (!slabs) return hipErrorOutOfMemory;
   }
   hipLaunchKernelGGL(kern, dim3(gx * gy * splits), dim3(256 * KH), lds, st, a, sps, slabs);

@@ -63,8 +63,10 @@ hipError_t launch_fp8_scale_update(float* slots, int n, hipStream_t st);
 // conv_wgrad.hip
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st);
 int wgrad_halo_tw(const WgradArgs& a);
-// accumulator slabs of the weight-gradient kernels (one buffer per stream) and the launch that folds them into dW, wgrad_halo.hip
-void* wgrad_slabs(hipStream_t st, size_t bytes);
+// per-stream scratch for partial results that a follow-up launch on the SAME stream folds in a fixed order: the accumulator slabs of
+// the weight-gradient kernels (wgrad_fold_kernel) and the per-workgroup rows of the BatchNorm-backward reduce pass (bn_bwd_sums_kernel);
+// the launches that fold them, wgrad_halo.hip
+void* stream_scratch(hipStream_t st, size_t bytes);
 hipError_t launch_wgrad_fold(const void* slabs, float* dw, int C, int gx, int gy, int splits, int taps, int kh_n, hipStream_t st);
 hipError_t launch_stem_wgrad_fold(const void* slabs, float* dw, int nwg, hipStream_t st);
 hipError_t launch_wgrad_halo(int dtype, const WgradArgs& a, int tw, hipStream_t st);

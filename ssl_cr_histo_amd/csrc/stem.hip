@@ -947,7 +947,7 @@ static hipError_t launch_stem_wgrad_t(const StemWgradArgs& a, const BnBwdArgs& b
   // every workgroup holds a partial of the SAME 64 x 147 weights: slabs + the ordered fold (wgrad_halo.hip), in every dtype
   f32x4_t* slabs = nullptr;
   if (grid > 1) {
-    slabs = reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t)));
+    slabs = reinterpret_cast<f32x4_t*>(stream_scratch(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t)));
     if (!slabs) return hipErrorOutOfMemory;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a, b, th, tw, ntiles, slabs);
@@ -978,7 +978,7 @@ static hipError_t launch_stem_wgrad_pool2(const StemWgradArgs& a, const BnBwdArg
   int grid = ntiles < 256 ? ntiles : 256;          // one 12-wave workgroup per CU (143 KiB of LDS)
   f32x4_t* slabs = nullptr;
   if (grid > 1) {
-    slabs = reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t)));
+    slabs = reinterpret_cast<f32x4_t*>(stream_scratch(st, (size_t)grid * 14 * 256 * sizeof(f32x4_t)));
     if (!slabs) return hipErrorOutOfMemory;
   }
   hipLaunchKernelGGL(kern, dim3(grid), dim3(768), lds, st, a, b, th, tw, ntiles, slabs);

@@ -392,7 +392,7 @@ hipError_t launch_stem_wgrad_fold(const void* slabs, float* dw, int nwg, hipStre
 // One entry per stream, 64 entries, least-recently-used eviction (logged once: it costs a device synchronise): a 65th stream (virtual-rank tests create a stream per context
 // and drop it) takes over the oldest entry after a device synchronise -- never a silent fall-back to the atomic path, whose
 // summation order differs -- and an evicted or destroyed stream's slab is freed instead of leaking.
-void* wgrad_slabs(hipStream_t st, size_t bytes) {
+void* stream_scratch(hipStream_t st, size_t bytes) {
   struct Slab { hipStream_t st; void* p; size_t cap; unsigned long long used; };
   constexpr int NSLAB = 64;
   static Slab slabs[NSLAB];
@@ -474,7 +474,7 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   // accumulator slabs + the ordered fold when there is more than one split (every dtype)
   f32x4_t* slabs = nullptr;
   if (splits > 1) {
-    slabs = reinterpret_cast<f32x4_t*>(wgrad_slabs(st, (size_t)gx * gy * splits * 36 * 256 * KH * sizeof(f32x4_t)));
+    slabs = reinterpret_cast<f32x4_t*>(stream_scratch(st, (size_t)gx * gy * splits * 36 * 256 * KH * sizeof(f32x4_t)));
     if (!slabs) return hipErrorOutOfMemory;        // (no atomic path to fall back to: its summation order would differ)
   }
   hipLaunchKernelGGL(kern, dim3(gx * gy * splits), dim3(256 * KH), lds, st, a, tps, ntiles, slabs);
