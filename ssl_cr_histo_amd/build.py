@@ -10,6 +10,13 @@ LIB = os.path.join(HERE, "libsslcr.so")
 SOURCES = ["conv_igemm.hip", "conv_halo.hip", "conv_halo256.hip", "conv_h16.hip", "conv_pp64.hip", "conv_dma.hip", "conv_fp8.hip", "conv_wgrad.hip", "wgrad_halo.hip","stem.hip", "stem_pool.hip", "augment.hip", "bn_eltwise.hip", "heads.hip", "optim.hip",
            "engine.cpp", "capi.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fvisibility=hidden"]
+# No SLP vectoriser where a wave's VALU work runs BESIDE its SIMD partner's MFMA stream (the ping-pong conv, the role-split stem
+# backward): the vectoriser turns pairs of fp32 operations into v_pk_add_f32 / v_pk_fma_f32, and next to a full-rate MFMA stream a
+# packed fp32 instruction gets issued once per ~140 cycles where a plain VALU instruction gets 1.3 per MFMA
+# (profiles/r04_partner_instruction_cost.txt).  Same box: conv3x3_pp64 -2.4 ... -4 % per launch, stem_wgrad_pool2 -2 %, and the
+# kernels fit their registers without spilling (256 + 12-32 B of scratch -> 228-236).  Neutral on the barrier-locked kernels
+# (conv3x3_h16, conv3x3_halo256, conv_dma: left alone), harmful on wgrad3x3_halo (+57 % on <16,1>: left alone).
+PER_FILE_FLAGS = {"conv_pp64.hip": ["-fno-slp-vectorize"], "stem.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(out, deps):
@@ -41,7 +48,7 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + headers):
-            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + PER_FILE_FLAGS.get(s, []) + ["-x", "hip", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
