@@ -56,6 +56,14 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+        # a .hip object without device code means the HOST pass dropped the kernels without a diagnostic (seen in round 4: a
+        # device-only type in a kernel body; hipcc returned 0 and the launches compiled to nothing)
+        if s.endswith(".hip"):
+            obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
+            with open(obj, "rb") as f:
+                if b".hip_fatbin" not in f.read():
+                    os.remove(obj)
+                    raise RuntimeError(f"{s}: the object carries no device code (.hip_fatbin missing) -- kernels dropped by the host pass")
     # exactly the entry points include/sslcr.h declares are exported: -fvisibility=hidden + the header's visibility push covers
     # the functions, the version script also makes the compiler-generated kernel handles and template instances local
     vmap = os.path.join(objdir, "exports.map")

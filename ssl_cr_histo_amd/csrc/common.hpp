@@ -179,6 +179,31 @@ __device__ __forceinline__ void st16(void* p, const u32x4_t& v) { *reinterpret_c
 __device__ __forceinline__ u32x4_t ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
 __device__ __forceinline__ void st16_nt(void* p, const u32x4_t& v) { __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(p)); }
 
+// global -> LDS DMA in its MUBUF form (buffer_load_dwordx4 ... lds): lane l's 16 bytes at (base + voff + soff) land at dst + 16 l, no
+// registers on the way.  Why not global_load_lds: that is a FLAT-family instruction, and after a FLAT instruction that touches LDS the
+// compiler's wait-count pass is in its "pending flat" state, in which EVERY wait for an LDS read becomes s_waitcnt lgkmcnt(0) --
+// including the fragment read issued one instruction earlier -- until the next vmcnt(0) + lgkmcnt(0) pair.  In the DMA-fed conv
+// kernels that put a full LDS round trip in front of the first MFMA of two steps out of three (round 4, from the ISA); behind a
+// buffer load the waits stay counted (lgkmcnt(4), (3), (3), (2) ... in front of the MFMA that needs the fragment).  A voff at or
+// beyond `bytes` reads zeros (raw-buffer range check): the padding page of the gather kernels for free.
+// (device pass only: the resource type does not exist in the host pass)
+struct LdsDma {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t r;
+#endif
+  __device__ __forceinline__ void init(const void* base, unsigned bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+#endif
+  }
+  // voff: per-lane byte offset (VGPR), soff: wave-uniform byte offset (SGPR); dst: wave-uniform LDS address (goes to M0)
+  __device__ __forceinline__ void load16(void* dst, int voff, int soff) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)dst, 16, voff, soff, 0, 0);
+#endif
+  }
+};
+
 // Weight tiles sit in LDS in MFMA-fragment order: kout row r = q*(4TK) + t*4 + j of a 16*TK-row block (q = fragment lane>>2,
 // t = MFMA tile, j = lane&3 -- the permutation that gives a lane 4*TK consecutive output channels) is stored at row
 // t*16 + q*4 + j, so the 16 lanes of a fragment read 16 CONSECUTIVE LDS rows and the (row&7) XOR swizzle is conflict-free

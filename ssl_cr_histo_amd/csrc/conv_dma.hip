@@ -18,8 +18,6 @@
 
 namespace sslcr {
 
-__device__ __attribute__((aligned(128))) uint32_t g_conv_zero_page[32];   // zero-initialised: the padding source
-
 template <typename T> struct MmaD;
 template <> struct MmaD<bf16_t> {
   __device__ static __forceinline__ void run(const u32x4_t& a, const u32x4_t& b, f32x4_t& c) {
@@ -98,7 +96,17 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
   const char* xg = reinterpret_cast<const char*>(a.x);
   const int slot = lane & 7;
   int h0[PLD], w0[PLD];
-  const char* rowp[PLD];
+  // Both operands come in by the MUBUF form of the DMA (LdsDma, common.hpp: behind global_load_lds every fragment wait of the step
+  // was lgkmcnt(0)).  The input's resource starts at the FIRST IMAGE of this workgroup's pixel block, so a lane's byte offset fits
+  // 32 bits whatever the batch (config 5's layer2.0 input is 2.3 GB); a position in the zero padding (or past M) gets an offset
+  // beyond the resource's range and reads zeros -- the range check is the padding page.
+  const int n_first = m0 / PHW;
+  const size_t img_bytes = (size_t)a.H * a.W * a.C * sizeof(T);
+  const size_t left = (size_t)(a.N - n_first) * img_bytes;
+  LdsDma xdma, wdma;
+  xdma.init(xg + (size_t)n_first * img_bytes, left < 0x80000000ull ? (unsigned)left : 0x80000000u);
+  constexpr int OOR = (int)0xfffffff0u;
+  int rowoff[PLD];
 #pragma unroll
   for (int i = 0; i < PLD; ++i) {
     const int rr = i * 32 + wave * 8 + (lane >> 3);
@@ -111,9 +119,9 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
       ph = ph * pmul + off_h; pw = pw * pmul + off_w;
       h0[i] = a.transposed ? (ph + a.pad) >> tsh : ph * a.stride - a.pad;
       w0[i] = a.transposed ? (pw + a.pad) >> tsh : pw * a.stride - a.pad;
-      rowp[i] = xg + ((long)n * a.H * a.W + (long)h0[i] * a.W + w0[i]) * (long)(a.C * (int)sizeof(T)) + pc16;
+      rowoff[i] = (int)(((long)(n - n_first) * a.H * a.W + (long)h0[i] * a.W + w0[i]) * (long)(a.C * (int)sizeof(T))) + pc16;
     } else {
-      h0[i] = -(1 << 24); w0[i] = 0; rowp[i] = xg;           // never in range
+      h0[i] = -(1 << 24); w0[i] = 0; rowoff[i] = 0;          // never in range
     }
   }
   int wsrc[WLD];
@@ -125,8 +133,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     const int krow = blk * 64 + ((x >> 2) & 3) * 16 + (x >> 4) * 4 + (x & 3);
     wsrc[i] = (int)((((size_t)(k0 + krow) * RS) * a.C + (slot ^ (rr & 7)) * EPC) * sizeof(T));
   }
-  const char* wg = reinterpret_cast<const char*>(a.w);
-  const char* zpage = reinterpret_cast<const char*>(g_conv_zero_page) + slot * 16;
+  wdma.init(a.w, (unsigned)((size_t)a.K * RS * a.C * sizeof(T)));
 
   int it_tap = __builtin_ctz(tmask), it_slab = 0;      // issue() is called for steps 0,1,2,... in order
   auto issue = [&](int stage) {
@@ -141,18 +148,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
     const int th = e_h - r, tw = e_w - s;
     const int dh = a.transposed ? (tsh ? th >> 1 : -r) : r, dw = a.transposed ? (tsh ? tw >> 1 : -s) : s;
     const bool tap_ok = !tsh || ((th | tw) & 1) == 0;
-    const long uoff = ((long)(dh * a.W + dw) * a.C + c0) * (long)sizeof(T);
+    const int uoff = ((dh * a.W + dw) * a.C + c0) * (int)sizeof(T);
     char* sb = smem + stage * STG;
 #pragma unroll
     for (int i = 0; i < PLD; ++i) {
       const bool ok = tap_ok && (unsigned)(h0[i] + dh) < (unsigned)a.H && (unsigned)(w0[i] + dw) < (unsigned)a.W;
-      const char* src = ok ? rowp[i] + uoff : zpage;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sb + (i * 32 + wave * 8) * 128), 16, 0, 0);
+      xdma.load16(sb + (i * 32 + wave * 8) * 128, ok ? rowoff[i] + uoff : OOR, 0);
     }
-    const char* wtap = wg + ((size_t)tap * a.C + c0) * sizeof(T);
+    const int wtap = (tap * a.C + c0) * (int)sizeof(T);
 #pragma unroll
-    for (int i = 0; i < WLD; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(wtap + wsrc[i]), (lptr_t)(sb + BB + (i * 32 + wave * 8) * 128), 16, 0, 0);
+    for (int i = 0; i < WLD; ++i) wdma.load16(sb + BB + (i * 32 + wave * 8) * 128, wsrc[i], wtap);
   };
 
   // fragment addresses: per-lane base (row & 7 == li & 7 for every fragment row) + immediates

@@ -54,6 +54,15 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 #define SSLCR_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0f70) /* vmcnt(0), lgkmcnt/expcnt untouched */
+// A barrier WITHOUT the workgroup fence of __syncthreads() (which is s_waitcnt lgkmcnt(0) first -- a wait for the fragment read
+// issued two MFMAs earlier).  Enough wherever no ds_write is pending and what the barrier orders are (a) this wave's completed DMA
+// (explicit vmcnt(0) in front) or (b) fragment reads whose MFMAs have already been issued, i.e. whose data has arrived.  The
+// "memory" clobber keeps the compiler from moving LDS accesses across it.
+#ifndef SSLCR_H16_FENCED_BARRIERS
+#define SSLCR_BARE_BARRIER() asm volatile("s_barrier" ::: "memory")
+#else
+#define SSLCR_BARE_BARRIER() __syncthreads()
+#endif
 
 // phase timing for tools/microbench/h16_phase_bench.hip (-DSSLCR_H16_PROF; compiled out otherwise): per wave of workgroup 0, shader
 // cycles of a stage spent waiting for the weight DMA, at the publish (P) and free (F) barriers, in the stage-end halo swap and in
@@ -157,14 +166,29 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
       edge |= (unsigned long long)((hr == 0) | ((hr == HH - 1) << 1) | ((hc == 0) << 2) | ((hc == HWD - 1) << 3)) << (4 * i);
     }
   }
-  // weight DMA: instruction i of this wave fills LDS rows [i*(NT/8) + wave*8, +8) of a tap; lane -> (row, 16-byte slot)
-  int wsrc[WLD];
-#pragma unroll
-  for (int i = 0; i < WLD; ++i) {
-    const int rr = i * (NT / 8) + wave * 8 + (lane >> 3);
+  // weight DMA.  Only ONE wave of each SIMD's pair issues it -- the YOUNGER one (waves 4-7; with WK = 1 there is no pair and all
+  // four load).  The older wave of a pair wins the matrix pipe (profiles/r04_partner_instruction_cost.txt: 94 % of it), so after
+  // every barrier the younger wave sits out the older one's MFMAs anyway: that is where its 1 KiB DMA instructions (60-180 cycles
+  // of issue each, MI355X_MICROARCH.md) cost nothing, instead of both waves of a SIMD issuing theirs at the same moment with the
+  // pipe idle.  Instruction i of loader wave lw fills LDS rows [i*32 + lw*8, +8) of a tap; lane -> (row, 16-byte slot).  wperm_inv
+  // permutes bit fields, so row i*32 + r comes from kout row wperm_inv(i*32) + wperm_inv(r): ONE per-lane source offset, the
+  // instruction's share is wave-uniform (soffset).
+#ifndef SSLCR_H16_ALL_LOAD
+  const bool loader = WK == 1 || wave >= 4;
+  constexpr int WLI = BKO / 32;               // DMA instructions per loader wave per tap
+  const int lw = wave & 3;
+#else
+  const bool loader = true;                   // (the round-3 split: every wave loads its share, for A/B builds)
+  constexpr int WLI = WLD;
+  const int lw = wave;
+#endif
+  constexpr int WROWS = BKO / WLI;            // LDS rows between a wave's consecutive instructions (32, or NT/8 when all load)
+  int wsrc0;
+  {
+    const int rr = lw * 8 + (lane >> 3);
     const int krow = wperm_inv<TK>(rr);
     const int c16 = (lane & 7) ^ (rr & 7);
-    wsrc[i] = (int)(((size_t)krow * 9 * a.C + c16 * EPC) * sizeof(T));
+    wsrc0 = (int)(((size_t)krow * 9 * a.C + c16 * EPC) * sizeof(T));
   }
   // fragment addresses: everything but these 8 registers is an immediate offset
   int Bb[3][2], Ab[2];
@@ -246,14 +270,18 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
       if ((hvalid >> i) & 1u) st16(s_halo + st_off[i], hreg[i]);
   };
   // DMA the three taps tap0..tap0+2 of (kout block k0, slab) into ring half `half`
+  // the DMA is the MUBUF form (LdsDma, common.hpp): behind global_load_lds 12 of a stage's 18 steps began with s_waitcnt lgkmcnt(0)
+  LdsDma wdma;
+  wdma.init(wg, 0x7fffffffu);
   auto dma_w = [&](int k0, int slab, int tap0, int half) {
+    if (!loader) return;
 #pragma unroll
     for (int tt = 0; tt < TPB; ++tt) {
-      const char* src = wg + ((size_t)k0 * 9 * a.C + (size_t)(tap0 + tt) * a.C + slab * CE) * sizeof(T);
+      const int soff = (int)(((size_t)k0 * 9 * a.C + (size_t)(tap0 + tt) * a.C + slab * CE) * sizeof(T));
 #pragma unroll
-      for (int i = 0; i < WLD; ++i) {
-        char* dst = s_w + (half * TPB + tt) * WBUF + (i * (NT / 8) + wave * 8) * 128;
-        __builtin_amdgcn_global_load_lds((gptr_t)(src + wsrc[i]), (lptr_t)dst, 16, 0, 0);
+      for (int i = 0; i < WLI; ++i) {
+        char* dst = s_w + (half * TPB + tt) * WBUF + (i * WROWS + lw * 8) * 128;
+        wdma.load16(dst, wsrc0, soff + wperm_inv<TK>(i * WROWS) * 9 * a.C * (int)sizeof(T));
       }
     }
   };
@@ -270,10 +298,21 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
   auto frags = [&](int buf, int step, const char* ringg) {     // ringg: the ring half holding tap (step>>1)'s group
     const int tap = step >> 1, kk = step & 1;
     const int r = tap / 3, s = tap - 3 * r;
+    // read order = the order in which the step's MFMAs (t-major) first need a fragment: A0, then every B, then A1.. -- the reads
+    // are issued one per two MFMAs of the previous step, so B[TP-1] is requested 11 MFMAs before its first use instead of 5
+    // (SSLCR_H16_FRAG_ORDER=0: A first, the round-3 order, for A/B builds)
+#ifndef SSLCR_H16_FRAG_AB
+    A[buf][0] = ld16(ringg + Ab[kk] + s * WBUF);
+#pragma unroll
+    for (int p = 0; p < TP; ++p) B[buf][p] = ld16(s_halo + Bb[s][kk] + (p + r) * (PITCH * 128));
+#pragma unroll
+    for (int t = 1; t < TK; ++t) A[buf][t] = ld16(ringg + Ab[kk] + s * WBUF + t * 2048);
+#else
 #pragma unroll
     for (int t = 0; t < TK; ++t) A[buf][t] = ld16(ringg + Ab[kk] + s * WBUF + t * 2048);
 #pragma unroll
     for (int p = 0; p < TP; ++p) B[buf][p] = ld16(s_halo + Bb[s][kk] + (p + r) * (PITCH * 128));
+#endif
   };
 
   // ---- pipeline fill: halo of (first item, slab 0) and ring half 0 <- taps 0..2
@@ -377,7 +416,7 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
         H16_T(tp0);
         SSLCR_WAIT_VM0();
         H16_T(tp1);
-        __syncthreads();                                  // P
+        SSLCR_BARE_BARRIER();                             // P
         H16_T(tp2);
         H16_ACC(0, tp1 - tp0); H16_ACC(1, tp2 - tp1);
         if (i == 8) {
@@ -389,7 +428,7 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
       }
       if (!WR && (i == 5 || i == 11)) {
         H16_T(tf0);
-        __syncthreads();                                  // F
+        SSLCR_BARE_BARRIER();                             // F (the reads of the released half fed MFMAs that have been issued)
         H16_T(tf1);
         H16_ACC(2, tf1 - tf0);
         if (i == 5) dma_w(cur.k0, slab, 6, wb); else dma_w(nxt.k0, nslab, 0, wb ^ 1);
@@ -397,7 +436,7 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
       }
     }
     H16_T(ts0);
-    __syncthreads();                          // every wave is done with this stage's halo
+    SSLCR_BARE_BARRIER();                     // every wave is done with this stage's halo (its last reads fed step 17's MFMAs)
     store_halo();
     __syncthreads();
     H16_T(ts1);

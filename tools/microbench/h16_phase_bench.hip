@@ -17,6 +17,8 @@ using namespace sslcr;
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 640, H = argc > 2 ? atoi(argv[2]) : 32, C = argc > 3 ? atoi(argv[3]) : 128;
   const int op = argc > 4 ? atoi(argv[4]) : 0;
+  // data: 0 random bf16 around +-1 (dense), 1 the same with half of the INPUT values zero (what a ReLU leaves), 2 all input values equal
+  const int data = argc > 5 ? atoi(argv[5]) : 0;
   const size_t elems = (size_t)N * H * H * C;
   uint16_t *x, *y, *r, *w;
   float *stats, *vec;
@@ -24,6 +26,9 @@ int main(int argc, char** argv) {
   hipMalloc(&stats, 256 * 4 * 2 * C * 4 * 2); hipMalloc(&vec, 4 * C * 4);
   std::vector<uint16_t> hx(1 << 20);
   for (size_t i = 0; i < hx.size(); ++i) hx[i] = (uint16_t)(0x3c00 + (rand() & 0x3ff) + ((rand() & 1) << 15));     // random bf16 around +-1
+  std::vector<uint16_t> hw(hx);                                    // weights stay dense random
+  if (data == 1) for (size_t i = 0; i < hx.size(); ++i) if (rand() & 1) hx[i] = 0;
+  if (data == 2) for (size_t i = 0; i < hx.size(); ++i) hx[i] = 0x3f80;
   for (size_t o = 0; o < elems; o += hx.size()) {
     const size_t n = elems - o < hx.size() ? elems - o : hx.size();
     hipMemcpy(x + o, hx.data(), n * 2, hipMemcpyHostToDevice);
@@ -31,7 +36,7 @@ int main(int argc, char** argv) {
   }
   for (size_t o = 0; o < (size_t)C * 9 * C; o += hx.size()) {
     const size_t n = (size_t)C * 9 * C - o < hx.size() ? (size_t)C * 9 * C - o : hx.size();
-    hipMemcpy(w + o, hx.data(), n * 2, hipMemcpyHostToDevice);
+    hipMemcpy(w + o, hw.data(), n * 2, hipMemcpyHostToDevice);
   }
   std::vector<float> hv(4 * C, 0.5f);
   hipMemcpy(vec, hv.data(), 4 * C * 4, hipMemcpyHostToDevice);
@@ -55,8 +60,9 @@ int main(int argc, char** argv) {
   hipEventElapsedTime(&ms, e0, e1);
   unsigned long long prof[16][8];
   hipMemcpyFromSymbol(prof, HIP_SYMBOL(g_h16_prof), sizeof(prof));
-  printf("N=%d %dx%d C=K=%d op=%d: %.1f us/launch, %.1f TF/s (MFMA-only floor of a stage: 2 waves x 288 MFMAs x 16 cycles = 9216 cycles per SIMD)\n", N, H, H, C, op,
-         ms * 1e3 / reps, 2.0 * elems * C * 9 / (ms / reps * 1e-3) / 1e12);
+  // implied shader clock: workgroup 0's cycle count over the launch's duration (the launch is one persistent walk per workgroup)
+  printf("N=%d %dx%d C=K=%d op=%d data=%d: %.1f us/launch, %.1f TF/s, %.2f GHz implied (MFMA-only floor of a stage: 2 waves x 288 MFMAs x 16 cycles = 9216 cycles per SIMD)\n",
+         N, H, H, C, op, data, ms * 1e3 / reps, 2.0 * elems * C * 9 / (ms / reps * 1e-3) / 1e12, (double)prof[0][6] / (ms * 1e3 / reps) * 1e-3);
   for (int wv = 0; wv < 8; wv += 3) {
     const double st = (double)prof[wv][5];
     printf("  wave %d: %4.0f stages, per stage %7.0f cycles: weight-DMA wait %6.0f, P barriers %6.0f, F barriers %6.0f, halo swap %6.0f, epilogue %6.0f\n", wv, st,
