@@ -68,7 +68,9 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
     stats = None
     if want_stats:
         rows = L.lib().sslcr_conv2d_partial_rows(d)
-        stats = torch.empty((rows, 2, K), dtype=torch.float32, device=x.device)
+        # NaN-poisoned: the launch must write every row it announced (a row left as found once went unnoticed here and blew up
+        # the engine's BatchNorm, whose scratch is reused)
+        stats = torch.full((rows, 2, K), float("nan"), dtype=torch.float32, device=x.device)
         d.stats = L.ptr(stats)
     global last_conv_kernel
     last_conv_kernel = L.lib().sslcr_conv2d_kernel_name(dt, d).decode()
@@ -106,7 +108,7 @@ def conv2d_fp8(x, w8, w_dequant, *, x_scale=1.0, in_scale=None, in_shift=None, i
     stats = None
     if want_stats:
         rows = L.lib().sslcr_conv2d_fp8_partial_rows(d)
-        stats = torch.empty((rows, 2, K), dtype=torch.float32, device=x.device)
+        stats = torch.full((rows, 2, K), float("nan"), dtype=torch.float32, device=x.device)
         d.stats = L.ptr(stats)
     L.check(L.lib().sslcr_conv2d_fp8(d, q, L.stream_ptr()))
     return (y, stats) if want_stats else y
@@ -168,7 +170,7 @@ def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False, x2=N
     stats = None
     if want_stats:
         rows = L.lib().sslcr_stem_partial_rows(d)
-        stats = torch.empty((rows, 2, 64), dtype=torch.float32, device=x_nchw.device)
+        stats = torch.full((rows, 2, 64), float("nan"), dtype=torch.float32, device=x_nchw.device)
         d.stats = L.ptr(stats)
     L.check(L.lib().sslcr_stem_conv(_dt(w_packed), d, L.stream_ptr()))
     return (y, stats) if want_stats else y

@@ -71,7 +71,7 @@ CONV_CASES = [
     (70, 32, 32, 64, 64, 3, 1, 1),     # 128x64 config
     (2, 8, 8, 512, 512, 3, 1, 1),      # halo kernel, 8-wide rows (2 images per tile), 8 channel slabs, BKO 128
     (4, 8, 8, 64, 64, 3, 1, 1),        # halo kernel, 8-wide, single slab
-    (320, 8, 8, 64, 512, 3, 1, 1),     # 80 tiles x 4 kout blocks = 320 items on 256 CUs: the last 64 run as 64-kout half-items
+    (320, 8, 8, 64, 512, 3, 1, 1),     # 80 tiles x 4 kout blocks = 320 items on 256 CUs: the last 64 run as 64-kout half-items (a second launch)
     (2, 16, 32, 128, 128, 3, 1, 1),    # halo kernel, 16-wide, 2 slabs
     (3, 24, 48, 64, 128, 3, 1, 1),     # halo kernel, several tiles per image
     (4, 8, 8, 512, 512, 3, 1, 1),      # 256-pixel halo kernel, 4 images x 8x8, 8 slabs
@@ -94,7 +94,7 @@ def test_conv_fwd_raw_stats(case, dtype):
     # the shapes added for a specific kernel must actually be served by it
     expect = {(33, 32, 32, 64, 256, 3, 1, 1): "conv3x3_h16_kernel", (10, 30, 34, 64, 128, 3, 2, 1): "conv_dma_kernel",
               (10, 30, 34, 128, 64, 3, 2, 1): "conv_dma_kernel", (9, 32, 32, 64, 128, 1, 2, 0): "conv_dma_kernel",
-              (4, 8, 8, 512, 512, 3, 1, 1): "conv3x3_halo256_kernel"}.get(case)
+              (4, 8, 8, 512, 512, 3, 1, 1): ", 8>", (320, 8, 8, 64, 512, 3, 1, 1): ", 8>"}.get(case)   # conv3x3_h16<..., 8>: four-image tiles
     if expect:
         assert expect in K.last_conv_kernel, K.last_conv_kernel
     if case == (70, 32, 32, 64, 64, 3, 1, 1) and dtype == 1:      # 280 tiles on 256 workgroups: the resident-filter walk
@@ -109,7 +109,7 @@ def test_conv_fwd_raw_stats(case, dtype):
 
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("shape", [(2, 12, 12, 128, 128), (2, 16, 16, 128, 128), (2, 8, 8, 256, 64), (4, 8, 8, 256, 128),
-                                   (1, 24, 16, 64, 64)])   # generic / halo256-16 / halo128-8 / halo256-8 / halo128-16
+                                   (1, 24, 16, 64, 64), (320, 8, 8, 64, 512)])   # generic / h16 / halo128-8 / h16 four-image tiles / halo128-16 / four-image tiles in two launches
 def test_conv_fwd_fused_prologue_epilogue(shape, dtype):
     K = _k()
     N, H, W, C, Ko = shape
@@ -124,6 +124,31 @@ def test_conv_fwd_fused_prologue_epilogue(shape, dtype):
     xt = q(F.relu(x * sc + sh), dtype)
     want = R.conv_fwd(xt, w, 1, 1, bias=bias, residual=res, relu=True)
     close(y, want, TOL[dtype], "fused conv")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("shape", [(4, 8, 8, 512, 512), (320, 8, 8, 64, 512), (12, 8, 8, 128, 128), (2, 32, 32, 128, 128)])
+def test_conv_eval_fused_epilogue_four_image_tiles(shape, dtype):
+    """bias + residual + ReLU with no prologue (the teacher's conv2 with the BatchNorm folded) on the four-image-tile form of
+    conv3x3_h16 -- one launch, and the 128-kout head + 64-kout tail pair of launches -- beside the 16x16-tile form"""
+    K = _k()
+    N, H, W, C, Ko = shape
+    x = q(rnd(31, (N, H, W, C)), dtype)
+    w = q(rnd(32, (Ko, 3, 3, C), 0.05), dtype)
+    bias = rnd(33, (Ko,))
+    res = q(rnd(34, (N, H, W, Ko)), dtype)
+    y = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, bias=bias.to(DEV), residual=to_dev(res, dtype), relu=True)
+    assert "conv3x3_h16_kernel" in K.last_conv_kernel and K.last_conv_kernel.endswith(", 8>" if H == 8 else ", 16>"), K.last_conv_kernel
+    want = R.conv_fwd(x, w, 1, 1, bias=bias, residual=res, relu=True)
+    close(y, want, TOL[dtype], "eval-fused conv")
+    # plain + statistics through the same shapes (the rows of a two-launch shape follow each other)
+    y2, stats = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), 1, 1, want_stats=True)
+    want2 = R.conv_fwd(x, w, 1, 1)
+    close(y2, want2, TOL[dtype], "conv raw")
+    s1, s2 = R.channel_stats(want2)
+    st = stats.double().sum(0).cpu()
+    close(st[0], s1, 2e-4 if dtype == 0 else 2e-3, "sum")
+    close(st[1], s2, 2e-4 if dtype == 0 else 2e-3, "sumsq")
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -859,7 +884,9 @@ SEG_CASES = [
     (3, 32, 32, 128, 128, 3, 1, 1, True),     # conv3x3_h16 ring form
     (44, 32, 32, 128, 128, 3, 1, 1, False),   # conv3x3_h16, more items than workgroups
     (2, 16, 16, 256, 256, 3, 1, 1, True),     # conv3x3_h16, two kout blocks
-    (8, 8, 8, 512, 512, 3, 1, 1, True),       # conv3x3_halo256 (four images per tile)
+    (8, 8, 8, 512, 512, 3, 1, 1, True),       # conv3x3_h16, four images per tile
+    (128, 8, 8, 512, 512, 3, 1, 1, True),     # ... 32 tiles x 4 kout blocks on 85 workgroups per segment: a kout-block-major walk skips blocks
+    (128, 8, 8, 512, 512, 3, 1, 1, False),
     (4, 64, 64, 64, 128, 3, 2, 1, False),     # conv_dma 3x3 / 2
     (8, 32, 32, 128, 256, 1, 2, 0, False),    # conv_dma 1x1 / 2
 ]
@@ -911,7 +938,7 @@ def test_conv_mask_front_end_segments_equal_separate_launches(case):
         d.mask_x, d.mask_scale, d.mask_shift, d.mask_mean = (L.ptr(t) for t in m_)
         d.seg_images, d.seg_stride = (seg, Cn) if seg else (0, 0)
         rows = L.lib().sslcr_conv2d_partial_rows(d)
-        st = torch.empty((rows, 2, Cn), dtype=torch.float32, device=x_.device)
+        st = torch.full((rows, 2, Cn), float("nan"), dtype=torch.float32, device=x_.device)
         d.stats = L.ptr(st)
         L.check(L.lib().sslcr_conv2d(1, d, L.stream_ptr()))
         return y, st
