@@ -175,6 +175,9 @@ typedef struct sslcr_bn_act_desc {      /* y = relu(x*scale+shift [+ res*rscale+
   const void* res; const float* rscale; const float* rshift;
   void* y; size_t pixels; int C; int relu;
   int nseg, seg_stride;   /* nseg > 1: the pixels are nseg equal segments, segment s uses (r)scale / (r)shift + s * seg_stride */
+  uint8_t* ybits;         /* optional (bf16 only): one bit per element of y in NHWC order, bit (e & 7) of byte e / 8 = (y[e] > 0) -- the
+                             ReLU mask of a residual block's output as BatchNorm backward wants it (sslcr_bn_bwd_desc.yact_bits):
+                             a sixteenth of the bytes of y */
 } sslcr_bn_act_desc;
 int sslcr_bn_act(int dtype, const sslcr_bn_act_desc* d, void* stream);
 
@@ -214,6 +217,8 @@ typedef struct sslcr_bn_bwd_desc {
      + s * seg_stride floats and sums + s * sums_stride doubles; count = elements per channel of ONE segment; dgamma / dbeta take
      the segments' contributions one after the other, segment 0 first.  Not with pool_dy. */
   int nseg, seg_stride, sums_stride;
+  const uint8_t* yact_bits;   /* instead of yact (bf16 only): its sign mask as written by sslcr_bn_act (ybits) -- g = dy where the bit is
+                                 set, 0 elsewhere: the same g, bit for bit, for 1/16 of yact's bytes */
 } sslcr_bn_bwd_desc;
 int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream);

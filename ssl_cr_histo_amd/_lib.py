@@ -40,7 +40,7 @@ BnFinalizeDesc = _S("BnFinalizeDesc", [("partials", vp), ("rows", i32), ("C", i3
                                        ("momentum", f32), ("eps", f32), ("replay", i32), ("sums_out", vp),
                                        ("sums_in", vp), ("stage", vp), ("nseg", i32), ("seg_stride", i32)])
 BnActDesc = _S("BnActDesc", [("x", vp), ("scale", vp), ("shift", vp), ("res", vp), ("rscale", vp), ("rshift", vp),
-                             ("y", vp), ("pixels", sz), ("C", i32), ("relu", i32), ("nseg", i32), ("seg_stride", i32)])
+                             ("y", vp), ("pixels", sz), ("C", i32), ("relu", i32), ("nseg", i32), ("seg_stride", i32), ("ybits", vp)])
 PoolFwdDesc = _S("PoolFwdDesc", [("x", vp), ("scale", vp), ("shift", vp), ("y", vp), ("argmax", vp)] +
                  [(k, i32) for k in ("N", "H", "W", "C", "OH", "OW")])
 PoolBwdDesc = _S("PoolBwdDesc", [("dy", vp), ("argmax", vp), ("x", vp), ("scale", vp), ("shift", vp), ("dx", vp)] +
@@ -49,7 +49,7 @@ BnBwdDesc = _S("BnBwdDesc", [("dy", vp), ("x", vp), ("yact", vp), ("scale", vp),
                              ("invstd", vp), ("sums", vp), ("dx", vp), ("gout", vp), ("pixels", sz), ("C", i32),
                              ("relu_from_x", i32), ("count", f64), ("pool_dy", vp), ("pool_argmax", vp), ("pH", i32),
                              ("pW", i32), ("pOH", i32), ("pOW", i32), ("pool_y", vp), ("g_in_reduce", i32), ("dgamma", vp), ("dbeta", vp),
-                             ("pg_scale", f32), ("nseg", i32), ("seg_stride", i32), ("sums_stride", i32)])
+                             ("pg_scale", f32), ("nseg", i32), ("seg_stride", i32), ("sums_stride", i32), ("yact_bits", vp)])
 LossDesc = _S("LossDesc", [("kind", i32), ("logits", vp), ("logits_t", vp), ("target_f", vp), ("target_i", vp),
                            ("dlogits", vp), ("out", vp), ("nx", i32), ("nu", i32), ("C", i32), ("lambda_u", f32),
                            ("inv_nx_global", f32), ("inv_nu_global", f32)])

@@ -151,7 +151,21 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
       if (r) v += fmaf(g[e], rsc[e], rsh[e]);
       f[e] = a.relu ? fmaxf(v, 0.f) : v;
     }
-    st16_nt(y + i * 16, Elem<T>::pack(f));
+    const u32x4_t packed = Elem<T>::pack(f);
+    st16_nt(y + i * 16, packed);
+    if constexpr (EPC == 8) {
+      // the sign mask of the STORED values (a positive float below half the smallest bf16 has become 0): what (y > 0) will read
+      if (a.ybits) {
+        unsigned b = 0;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned lo = packed[d] & 0xffffu, hi = packed[d] >> 16;
+          b |= ((lo - 1u) < 0x7fffu ? 1u : 0u) << (2 * d);          // 0x0001 .. 0x7fff: a positive bf16 (and a positive-signed NaN, the one
+          b |= ((hi - 1u) < 0x7fffu ? 1u : 0u) << (2 * d + 1);      //   case where (y > 0) says otherwise)
+        }
+        a.ybits[(size_t)blockIdx.y * total + i] = (uint8_t)b;
+      }
+    }
   }
 }
 
@@ -528,7 +542,12 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdArgs& a, size_t i, const flo
   } else {
     Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.dy) + i * 16), g);
   }
-  if (a.yact) {
+  if (EPC == 8 && a.yact_bits) {
+    const unsigned b = a.yact_bits[i];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e)
+      if (!((b >> e) & 1u)) g[e] = 0.f;
+  } else if (a.yact) {
     float ya[EPC];
     Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.yact) + i * 16), ya);
 #pragma unroll
@@ -568,6 +587,7 @@ __device__ __forceinline__ BnBwdArgs bn_bwd_segment(const BnBwdArgs& a) {
     if (a.dy) b.dy = reinterpret_cast<const char*>(a.dy) + off;
     if (a.x) b.x = reinterpret_cast<const char*>(a.x) + off;
     if (a.yact) b.yact = reinterpret_cast<const char*>(a.yact) + off;
+    if (a.yact_bits) b.yact_bits = a.yact_bits + (size_t)z * b.pixels * a.C / 8;
     if (a.dx) b.dx = reinterpret_cast<char*>(a.dx) + off;
     if (a.gout) b.gout = reinterpret_cast<char*>(a.gout) + off;
     const size_t so = (size_t)z * a.seg_stride;
@@ -877,7 +897,7 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a0, hipStream_t st) {
   BnBwdArgs a = a0;
   if (a.g_in_reduce) {      // the reduce pass left the masked gradient in gout: plain dy from here on
-    a.dy = a.gout; a.yact = nullptr; a.relu_from_x = 0; a.gout = nullptr; a.g_in_reduce = 0;
+    a.dy = a.gout; a.yact = nullptr; a.yact_bits = nullptr; a.relu_from_x = 0; a.gout = nullptr; a.g_in_reduce = 0;
   }
   if (a.pool_dy && a.nseg > 1) return hipErrorInvalidValue;
   if (a.pool_dy) {

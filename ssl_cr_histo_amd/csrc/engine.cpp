@@ -100,6 +100,7 @@ struct PassState {
   uint8_t* argmax = nullptr;
   struct {
     char *raw1, *raw2, *rawd, *y;
+    uint8_t* ybits;              // bf16 mode: one bit per element of y, (y > 0) -- what bn2's backward reduce pass reads instead of y
   } blk[8];
   BnSaved bn[20];
   float* E = nullptr;
@@ -214,6 +215,7 @@ struct sslcr_net {
   bool opt_packs_all = false;     // the optimizer work list rewrites every non-stem conv's train-mode shadow weights
   size_t grad_count = 0;
   PassState pass[3];
+  bool ybits_ok = false;         // the passes' mask bits are allocated back to back (what the segment forms assume)
   // heads state (fp32)
   int hN = 0;
   float *cat[3], *hact[3], *fi[3], *feats = nullptr, *hid = nullptr, *logits = nullptr, *dE[3], *dfeats = nullptr, *dhid = nullptr,
@@ -592,10 +594,14 @@ int alloc_passes(sslcr_net* n, int npass, int N, int H, int W) {
   auto take = [&](size_t per_pass) { return c.take(per_pass * npass); };   // (every per-pass size is a multiple of 128 bytes)
   const size_t s_raw0 = (size_t)N * d.oh0 * d.ow0 * 64 * es, s_pool = (size_t)N * d.ph * d.pw * 64 * es, s_arg = (size_t)N * d.ph * d.pw * 64;
   const size_t o_raw0 = take(s_raw0), o_pool = take(s_pool), o_arg = take(s_arg);
-  size_t o_blk[8][4], s_blk[8];
+  size_t o_blk[8][4], s_blk[8], o_bits[8], s_bits[8];
+  bool bits_ok = true;
   for (int i = 0; i < 8; ++i) {
     s_blk[i] = (size_t)N * d.lh[i] * d.lw[i] * kBlockCfg[i][1] * es;
     for (int j = 0; j < 4; ++j) o_blk[i][j] = (j == 2 && !n->blocks[i].has_ds) ? 0 : take(s_blk[i]);
+    s_bits[i] = (((size_t)N * d.lh[i] * d.lw[i] * kBlockCfg[i][1] / 8) + 127) / 128 * 128;
+    o_bits[i] = take(s_bits[i]);
+    if (s_bits[i] * 8 != (size_t)N * d.lh[i] * d.lw[i] * kBlockCfg[i][1]) bits_ok = false;      // padded: not contiguous across passes
   }
   const size_t s_bn = 20 * 4 * 512 * sizeof(float), s_E = (size_t)N * 512 * sizeof(float);
   const size_t o_bn = take(s_bn), o_E = take(s_E);
@@ -608,6 +614,7 @@ int alloc_passes(sslcr_net* n, int npass, int N, int H, int W) {
       ps.blk[i].raw1 = b + o_blk[i][0] + p * s_blk[i]; ps.blk[i].raw2 = b + o_blk[i][1] + p * s_blk[i];
       ps.blk[i].rawd = n->blocks[i].has_ds ? b + o_blk[i][2] + p * s_blk[i] : nullptr;
       ps.blk[i].y = b + o_blk[i][3] + p * s_blk[i];
+      ps.blk[i].ybits = (uint8_t*)(b + o_bits[i] + p * s_bits[i]);
     }
     float* f = (float*)(b + o_bn + p * s_bn);
     for (int i = 0; i < 20; ++i) {
@@ -617,6 +624,7 @@ int alloc_passes(sslcr_net* n, int npass, int N, int H, int W) {
     ps.E = (float*)(b + o_E + p * s_E);
     ps.N = N; ps.H = H; ps.W = W;
   }
+  n->ybits_ok = bits_ok;
   return 0;
 }
 
@@ -642,6 +650,21 @@ int forward_stem(sslcr_net* n, PassState& ps, const void* x, int in_f32, int N, 
   p.N = N; p.H = d.oh0; p.W = d.ow0; p.C = 64; p.OH = d.ph; p.OW = d.pw;
   TRY(launch_bn_relu_maxpool(dt, p, st));
   return 0;
+}
+
+// The ReLU mask of a block output as bits (sslcr_bn_act_desc.ybits, bf16 mode): bn2's backward reduce pass reads 1/16 of the bytes of y.
+// SSLCR_YBITS=0 keeps the tensor read (same-box A/B runs).
+bool ybits_on(const sslcr_ctx* c) {
+  static const bool on = [] { const char* e = getenv("SSLCR_YBITS"); return !e || atoi(e) != 0; }();
+  return on && c->dtype == DT_BF16;
+}
+// the bits that go with a saved block output (nullptr: not one of them)
+const uint8_t* ybits_of(const sslcr_net* n, const void* yact) {
+  if (!yact || !n->ybits_ok || !ybits_on(n->ctx)) return nullptr;
+  for (int p = 0; p < 3; ++p)
+    for (int i = 0; i < 8; ++i)
+      if (n->pass[p].blk[i].y == yact) return n->pass[p].blk[i].ybits;
+  return nullptr;
 }
 
 // the eight residual blocks + average pool from ps.pooled on.  nseg == 1: one pass of N images.  nseg > 1: ps is the FIRST of nseg
@@ -679,6 +702,7 @@ int forward_blocks(sslcr_net* n, PassState& ps, int N, int H, int W, int replay,
     e.x = ps.blk[i].raw2; e.scale = ps.bn[B.b2.bidx].scale; e.shift = ps.bn[B.b2.bidx].shift;
     e.y = ps.blk[i].y; e.pixels = (size_t)NT * oh * ow; e.C = B.c2.cout; e.relu = 1;
     if (segs) { e.nseg = nseg; e.seg_stride = seg_stride; }
+    if (n->ybits_ok && ybits_on(c)) e.ybits = ps.blk[i].ybits;
     if (B.has_ds) {
       ConvArgs ad = conv_args(B.ds, X, B.ds.w_fwd, ps.blk[i].rawd, NT, xh, xw);
       if (segs) ad.seg_images = N;
@@ -942,6 +966,7 @@ int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy,
   a.sums = sums; a.dx = dx; a.gout = gout; a.pixels = pixels; a.C = bn.C; a.relu_from_x = relu_from_x;
   if (nseg > 1) { a.nseg = nseg; a.seg_stride = seg_stride; a.sums_stride = sslcr_ctx::kBnSlot; }
   a.g_in_reduce = (g_in_reduce && yact && gout) ? 1 : 0;
+  a.yact_bits = ybits_of(n, yact);
   const bool synced = sharded(c) && c->bn_sync;
   if (n->rg[bn.pg] || n->rg[bn.pb]) {
     // dgamma/dbeta ride on the apply pass.  Synced BN: every rank holds the GLOBAL sums and the gradient all-reduce adds

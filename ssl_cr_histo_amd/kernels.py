@@ -251,15 +251,20 @@ def bn_finalize(partials, count, gamma, beta, *, running_mean=None, running_var=
     return scale, shift, mean, invstd
 
 
-def bn_act(x, scale, shift, *, res=None, rscale=None, rshift=None, relu=True, nseg=1):
-    """nseg > 1: x is nseg equal segments along its first dimension, scale / shift (/ rscale / rshift) are [nseg, C]."""
+def bn_act(x, scale, shift, *, res=None, rscale=None, rshift=None, relu=True, nseg=1, want_bits=False):
+    """nseg > 1: x is nseg equal segments along its first dimension, scale / shift (/ rscale / rshift) are [nseg, C].
+    want_bits (bf16): -> (y, bits uint8 [numel / 8]), bit (e & 7) of byte e >> 3 = (y.flatten()[e] > 0)  (sslcr_bn_act_desc.ybits)."""
     _chk(x, scale, shift, res, rscale, rshift)
     y = torch.empty_like(x)
     Cn = x.shape[-1]
     d = L.BnActDesc(L.ptr(x), L.ptr(scale), L.ptr(shift), L.ptr(res), L.ptr(rscale), L.ptr(rshift), L.ptr(y),
                     x.numel() // Cn, Cn, int(relu), nseg if nseg > 1 else 0, Cn if nseg > 1 else 0)
+    bits = None
+    if want_bits:
+        bits = torch.full((x.numel() // 8,), 0xa5, dtype=torch.uint8, device=x.device)
+        d.ybits = L.ptr(bits)
     L.check(L.lib().sslcr_bn_act(_dt(x), d, L.stream_ptr()))
-    return y
+    return (y, bits) if want_bits else y
 
 
 def bn_relu_maxpool(x, scale, shift):
@@ -301,7 +306,7 @@ def avgpool_bwd(dy, shape, dtype):
 
 
 def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, want_g=False, count=None, pool=None,
-           g_in_reduce=False, nseg=1, dgamma=None, dbeta=None):
+           g_in_reduce=False, nseg=1, dgamma=None, dbeta=None, yact_bits=None):
     """-> (dx, sums[2,C] fp64, g|None).  g_in_reduce: the reduce pass writes g and the apply pass reads it (needs yact, want_g).
     nseg > 1: x is nseg equal segments along its first dimension with constants [nseg, C]; sums come back [nseg, 2, C];
     dgamma / dbeta (fp32 [C], accumulated into) take every segment's contribution."""
@@ -318,6 +323,9 @@ def bn_bwd(dy, x, scale, shift, mean, invstd, *, yact=None, relu_from_x=False, w
                     None, None, 0, 0, 0, 0, None, int(g_in_reduce))
     if dgamma is not None:
         d.dgamma, d.dbeta, d.pg_scale = L.ptr(dgamma), L.ptr(dbeta), 1.0
+    if yact_bits is not None:     # the sign mask of yact as sslcr_bn_act wrote it: read instead of yact (which stays in the descriptor)
+        _chk(yact_bits)
+        d.yact_bits = L.ptr(yact_bits)
     if nseg > 1:
         d.nseg, d.seg_stride, d.sums_stride = nseg, Cn, 2 * Cn
     if pool is not None:          # pool = (pooled_dy [N,OH,OW,C], argmax u8[, pooled output y]): dy arrives through the stem max-pool

@@ -570,6 +570,38 @@ def test_bn_backward(mode, dtype):
         close(sums2, sums, 1e-12, "sums with g written by the reduce pass")
 
 
+@pytest.mark.parametrize("nseg", [1, 3])
+def test_relu_mask_as_bits_through_bn_act_and_bn_backward(nseg):
+    """sslcr_bn_act_desc.ybits / sslcr_bn_bwd_desc.yact_bits (bf16): the block output's sign mask as one bit per element -- written by the
+    forward's bn_act from the STORED values, read by bn2's backward reduce pass instead of the tensor: the same g, sums and dx, bit for bit,
+    plain and as segments."""
+    K = _k()
+    n, H, W, C = 4, 6, 10, 128
+    N = nseg * n
+    x = to_dev(rnd(301, (N, H, W, C)), 1)
+    res = to_dev(rnd(302, (N, H, W, C)), 1)
+    shp = (nseg, C) if nseg > 1 else (C,)
+    sc, sh = (rnd(303, shp).abs() * 0.5 + 0.25).to(DEV), rnd(304, shp, 0.3).to(DEV)
+    # tiny positive values too: a float below half the smallest bf16 is stored as 0 and its bit must be 0
+    sh.view(-1)[:8] = 1e-41
+    sc.view(-1)[:8] = 0.0
+    res[..., :8] = 0
+    y, bits = K.bn_act(x, sc, sh, res=res, relu=True, nseg=nseg, want_bits=True)
+    y_plain = K.bn_act(x, sc, sh, res=res, relu=True, nseg=nseg)
+    assert torch.equal(y.view(torch.int16), y_plain.view(torch.int16))
+    want = (y.float().flatten() > 0).view(-1, 8).to(torch.int32)
+    got = ((bits.to(torch.int32).view(-1, 1) >> torch.arange(8, device=DEV, dtype=torch.int32).view(1, 8)) & 1)
+    assert torch.equal(got, want)
+    dy = to_dev(rnd(305, (N, H, W, C)), 1)
+    mean, invstd = rnd(306, shp, 0.2).to(DEV), (rnd(307, shp).abs() + 0.5).to(DEV)
+    for gir in (False, True):
+        a = K.bn_bwd(dy, x, sc, sh, mean, invstd, yact=y, want_g=True, g_in_reduce=gir, nseg=nseg)
+        b = K.bn_bwd(dy, x, sc, sh, mean, invstd, yact=y, want_g=True, g_in_reduce=gir, nseg=nseg, yact_bits=bits)
+        assert torch.equal(a[0].view(torch.int16), b[0].view(torch.int16)) and torch.equal(a[1], b[1])
+        assert torch.equal(a[2].view(torch.int16), b[2].view(torch.int16))
+    assert float((a[2].float() != 0).float().mean()) > 0.2           # (the mask is not trivially empty)
+
+
 def test_linear_and_loss():
     K = _k()
     M, Kd, Nn = 37, 1024, 512
