@@ -3,10 +3,10 @@
 // stride-2 downsample convs.  None of these has a producer BatchNorm in its load path (their input is a materialised block
 // output), so neither operand needs registers on the way to LDS:
 //
-//   * per step (one tap, one 128-byte channel slab) each lane issues global_load_lds_dwordx4 for its share of the BP pixel
+//   * per step (one tap, one 128-byte channel slab) each lane issues an LDS DMA (buffer_load_dwordx4 ... lds) for its share of the BP pixel
 //     rows and BKO weight rows.  The lane picks its SOURCE 16-byte chunk so that the linear DMA placement is the XOR-
-//     swizzled (and, for weights, fragment-ordered) tile; a pixel that falls into the zero padding (or past M) reads a
-//     128-byte page of zeros instead -- no branches around memory operations, no ds_write, no staging VGPRs;
+//     swizzled (and, for weights, fragment-ordered) tile; a pixel that falls into the zero padding (or past M) gets an
+//     offset beyond the buffer resource's range, which reads zeros -- no branches around memory operations, no ds_write, no staging VGPRs;
 //   * step j+1 is requested before the MFMAs of step j and waited for (vmcnt(0)) right before the barrier that ends
 //     step j; scheduler fences keep the requests where they are written (the compiler otherwise sinks them to the wait);
 //   * 256 threads, each wave a 64 px x 64 kout register tile (16 MFMA per 8 fragment reads), two workgroups per CU so one
@@ -31,9 +31,6 @@ template <> struct MmaD<float> {
       c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a[e]), __uint_as_float(b[e]), c, 0, 0, 0);
   }
 };
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <typename T, int BP, int BKO>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {

@@ -11,7 +11,8 @@
 // ds_read -> wait -> 4 MFMA -> ds_read ...
 //
 // This kernel is built around those three facts:
-//   * weights go global -> LDS by DMA (global_load_lds_dwordx4, no registers, no ds_write): a whole ring half (3 taps) is
+//   * weights go global -> LDS by DMA (buffer_load_dwordx4 ... lds -- LdsDma, common.hpp; no registers, no ds_write; issued by the
+//     younger wave of each SIMD's pair): a whole ring half (3 taps) is
 //     issued right after the barrier that frees it and waited for once, just before the barrier that publishes it, three
 //     taps later.  The lane picks its SOURCE chunk so that the linear DMA placement is the swizzled, fragment-ordered tile.
 //   * the halo of the next stage is requested after the first weight wait of a stage, so the only vmcnt waits in the
@@ -50,19 +51,12 @@ __device__ __forceinline__ int wperm_inv(int rr) {
   return blk * B + q * (4 * TK) + t * 4 + j;
 }
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
 #define SSLCR_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0f70) /* vmcnt(0), lgkmcnt/expcnt untouched */
 // A barrier WITHOUT the workgroup fence of __syncthreads() (which is s_waitcnt lgkmcnt(0) first -- a wait for the fragment read
 // issued two MFMAs earlier).  Enough wherever no ds_write is pending and what the barrier orders are (a) this wave's completed DMA
 // (explicit vmcnt(0) in front) or (b) fragment reads whose MFMAs have already been issued, i.e. whose data has arrived.  The
 // "memory" clobber keeps the compiler from moving LDS accesses across it.
-#ifndef SSLCR_H16_FENCED_BARRIERS
 #define SSLCR_BARE_BARRIER() asm volatile("s_barrier" ::: "memory")
-#else
-#define SSLCR_BARE_BARRIER() __syncthreads()
-#endif
 
 // phase timing for tools/microbench/h16_phase_bench.hip (-DSSLCR_H16_PROF; compiled out otherwise): per wave of workgroup 0, shader
 // cycles of a stage spent waiting for the weight DMA, at the publish (P) and free (F) barriers, in the stage-end halo swap and in
@@ -101,10 +95,9 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
   constexpr int TH = TW, NI = 256 / (TW * TH), HH = TH + 2, HWD = TW + 2, PITCH = TW == 16 ? 24 : 10;
   constexpr int HP = TW == 16 ? HH * HWD : 256;   // staged halo pixels: the 18x18 halo, or the four images' interiors
   constexpr int NLD = (HP * 8 + NT - 1) / NT; // 16-byte halo loads per thread per stage
-  constexpr int WLD = BKO * 8 / NT;           // DMA instructions per thread per tap
   constexpr int TK = BKO / (16 * WK), TP = 4;
   constexpr int HBUF = NI * HH * PITCH * 128, WBUF = BKO * 128, TPB = 3;
-  static_assert(NLD <= 16 && WLD >= 1, "staging shape");
+  static_assert(NLD <= 16, "staging shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_halo = smem;
   constexpr int NRING = WR ? 3 : 2;           // tap groups held in LDS
@@ -187,16 +180,10 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
   // pipe idle.  Instruction i of loader wave lw fills LDS rows [i*32 + lw*8, +8) of a tap; lane -> (row, 16-byte slot).  wperm_inv
   // permutes bit fields, so row i*32 + r comes from kout row wperm_inv(i*32) + wperm_inv(r): ONE per-lane source offset, the
   // instruction's share is wave-uniform (soffset).
-#ifndef SSLCR_H16_ALL_LOAD
   const bool loader = WK == 1 || wave >= 4;
   constexpr int WLI = BKO / 32;               // DMA instructions per loader wave per tap
   const int lw = wave & 3;
-#else
-  const bool loader = true;                   // (the round-3 split: every wave loads its share, for A/B builds)
-  constexpr int WLI = WLD;
-  const int lw = wave;
-#endif
-  constexpr int WROWS = BKO / WLI;            // LDS rows between a wave's consecutive instructions (32, or NT/8 when all load)
+  constexpr int WROWS = BKO / WLI;            // LDS rows between a wave's consecutive instructions
   int wsrc0;
   {
     const int rr = lw * 8 + (lane >> 3);
@@ -316,19 +303,11 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
     const int r = tap / 3, s = tap - 3 * r;
     // read order = the order in which the step's MFMAs (t-major) first need a fragment: A0, then every B, then A1.. -- the reads
     // are issued one per two MFMAs of the previous step, so B[TP-1] is requested 11 MFMAs before its first use instead of 5
-    // (SSLCR_H16_FRAG_ORDER=0: A first, the round-3 order, for A/B builds)
-#ifndef SSLCR_H16_FRAG_AB
     A[buf][0] = ld16(ringg + Ab[kk] + s * WBUF);
 #pragma unroll
     for (int p = 0; p < TP; ++p) B[buf][p] = ld16(s_halo + Bb[s][kk] + ((TW == 16 ? p : 2 * p) + r) * (PITCH * 128));
 #pragma unroll
     for (int t = 1; t < TK; ++t) A[buf][t] = ld16(ringg + Ab[kk] + s * WBUF + t * 2048);
-#else
-#pragma unroll
-    for (int t = 0; t < TK; ++t) A[buf][t] = ld16(ringg + Ab[kk] + s * WBUF + t * 2048);
-#pragma unroll
-    for (int p = 0; p < TP; ++p) B[buf][p] = ld16(s_halo + Bb[s][kk] + ((TW == 16 ? p : 2 * p) + r) * (PITCH * 128));
-#endif
   };
 
   if (TW == 8) {          // the padding ring (and everything else) once; a stage rewrites the interiors only
