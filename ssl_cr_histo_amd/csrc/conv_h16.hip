@@ -1,6 +1,6 @@
-// 3x3 / stride 1 / pad 1 NHWC convolution on 16x16-pixel tiles: persistent, DMA-fed form of the LDS-halo kernel
-// (ResNet18 layer1-3 block convs forward and their dgrads through tap-flipped packs; conv_halo256.hip keeps the
-// 4-image x 8x8 layer4 shape and is the fallback).
+// 3x3 / stride 1 / pad 1 NHWC convolution on 256-pixel tiles -- a 16x16 patch of one image, or (TW = 8) four whole 8x8 images:
+// persistent, DMA-fed form of the LDS-halo kernel (ResNet18 layer1-4 block convs forward and their dgrads through tap-flipped
+// packs; conv_halo256.hip is the fallback for the shapes this one does not take).
 //
 // What the previous form lost, measured by ablation on the layer2 shape (N=640, 32x32, 128->128: 220 us, MFMA-only ~95 us):
 // removing the MFMAs left 137 us, the halo loads 47 us, the weight loads 50 us, the epilogue 52 us, the barriers 31 us --
