@@ -170,12 +170,17 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const BnActArgs a) {
 }
 
 static inline int ew_grid(size_t work_items) {
-  // 2048 workgroups: +4 % on bn_bwd_apply over 4096 (5.46 -> 5.69 TB/s); 8192+ is slower.  Initialised once, thread-safely
-  // (virtual ranks launch from several host threads); SSLCR_EW_CAP is read as a signed value and clamped to [256, 65535]
+  // THREE workgroups per CU (768 on the MI355X).  Same-box sweeps of the default step, r04 (gpurun_out/cap): 256 -> 17.0 ms,
+  // 512 15.86, 640 15.82, 768 15.73-15.80, 896 15.87, 1024 +0.03 over 768, 1536 / 2048 (the cap of rounds 2-4) / 3072 15.86-15.87,
+  // 40960 and up +2 ms (the per-workgroup constants).  tools/microbench/hbm_bench.hip agrees for a 2-read-1-write stream: 1024
+  // workgroups 6.16 TB/s, 2048 5.8, 4096 5.5 -- and more only again with one vector per thread and no prologue at all
+  // (81920 workgroups: 6.6 TB/s).  Initialised once, thread-safely (virtual ranks launch from several host threads);
+  // SSLCR_EW_CAP is read as a signed value and clamped to [256, 65535]
   static const size_t cap = [] {
     const char* e = getenv("SSLCR_EW_CAP");
-    long v = e ? strtol(e, nullptr, 10) : 256 * 8;
-    if (v < 256) v = e ? 256 : 256 * 8;
+    const long dflt = 3L * device_cus();
+    long v = e ? strtol(e, nullptr, 10) : dflt;
+    if (v < 256) v = e ? 256 : dflt;
     if (v > 65535) v = 65535;
     return (size_t)v;
   }();
