@@ -523,15 +523,20 @@ def main():
     out["library"] = {"path": os.path.relpath(_L.LIB_PATH, ROOT), "so_mtime": int(os.path.getmtime(_L.LIB_PATH)), "so_sha16": so_sha,
                       "build_mode": "in-tree hipcc --offload-arch=gfx950 (ssl_cr_histo_amd/build.py), loaded through ctypes; no JIT, no fallback"}
 
-    if rank == 0 and not args.no_roofline:
-        # roofline leg: same steps again with every conv launch bracketed by HIP events on its own stream
+    # roofline leg: same steps again with every conv launch bracketed by HIP events on its own stream.  EVERY rank runs these steps
+    # (a step of a sharded job is full of collectives: rank 0 stepping alone would wait for its peers for ever, and they for it
+    # at the final barrier); only rank 0 reads the table and writes the objects.
+    rows = []
+    nprof = max(2, min(5, args.steps))
+    if not args.no_roofline:
         eng.profile(True)
-        nprof = max(2, min(5, args.steps))
         for _ in range(nprof):
             step()
-        torch.cuda.synchronize()
-        rows = eng.profile_table()          # per kernel template instance, sorted by total time
+        barrier()
+        if rank == 0:
+            rows = eng.profile_table()      # per kernel template instance, sorted by total time
         eng.profile(False)
+    if rank == 0 and not args.no_roofline:
         peak = 157.3 if args.dtype == "fp32" else 2500.0
         hbm_rows = [r for r in rows if r["flops"] == 0]
         rows = [r for r in rows if r["flops"] > 0]
