@@ -182,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
       int rl = role[i];
       asm volatile("" : "+v"(rl));               // keep the unpacked form out of the loop-invariant set (it would cost 11 registers)
       const int idx = q.origin + (ok ? (rl & 0xffff) - rel_bias : 0);
-      hreg[i] = ld16(xg + (unsigned)idx * (unsigned)(64 * sizeof(T)));       // 32-bit offsets from a uniform base (tensors < 4 GB)
+      hreg[i] = ld16_nt(xg + (unsigned)idx * (unsigned)(64 * sizeof(T)));       // 32-bit offsets from a uniform base (tensors < 4 GB)
       hin |= (ok ? 1u : 0u) << i;
     }
   };
