@@ -74,6 +74,15 @@ int sslcr_conv2d_segments_ok(int dtype, const sslcr_conv_desc* d);      /* 1: th
 /* name of the kernel instance sslcr_conv2d would launch for this descriptor, spelled as rocprofv3 prints it (static string;
    lets tests and profiles tie a shape to the code path that serves it) */
 const char* sslcr_conv2d_kernel_name(int dtype, const sslcr_conv_desc* d);
+/* A downsampling BasicBlock's two convolutions of ONE input in one launch (torchvision BasicBlock.forward: `out = self.conv1(x)` and
+   `identity = self.downsample(x)` -- downsample[0] is the 1x1 / stride-2 projection -- of layer{2,3,4}[0], reached through
+   models/net.py:32,77): c1 is the 3x3 / stride 2 / pad 1 descriptor, ds the 1x1 / stride 2 / pad 0 descriptor with the same x, N, H, W,
+   C and K.  Both must be in the same mode: stats (train forward: raw output + BatchNorm partial rows, sslcr_conv2d_partial_rows(c1)
+   rows each) or bias (eval forward with the BatchNorm folded; relu honoured per descriptor).  Served where
+   sslcr_conv2d_s2_pair_ok returns 1 (bf16, 16x16-tileable OUTPUT maps, C % 64 == 0, K % 128 == 0, no prologue / residual); the
+   results equal two sslcr_conv2d calls. */
+int sslcr_conv2d_s2_pair(int dtype, const sslcr_conv_desc* c1, const sslcr_conv_desc* ds, void* stream);
+int sslcr_conv2d_s2_pair_ok(int dtype, const sslcr_conv_desc* c1, const sslcr_conv_desc* ds);
 
 /* ---- fp8 (OCP e4m3) forward conv path: BASELINE config 5, eval_Camelyon_SSL_CR.py:33-157 "fp8 MFMA conv path".
  *      Serves 3x3 / stride 1 / pad 1 convs with C % 128 == 0, K % 128 == 0 on 16x16-tileable maps (or 8x8 maps with N % 4 == 0):

@@ -79,6 +79,8 @@ SIGNATURES = {
     "sslcr_conv2d_partial_rows": (i32, [P(ConvDesc)]),
     "sslcr_conv2d_segments_ok": (i32, [i32, P(ConvDesc)]),
     "sslcr_conv2d_kernel_name": (C.c_char_p, [i32, P(ConvDesc)]),
+    "sslcr_conv2d_s2_pair": (i32, [i32, P(ConvDesc), P(ConvDesc), vp]),
+    "sslcr_conv2d_s2_pair_ok": (i32, [i32, P(ConvDesc), P(ConvDesc)]),
     "sslcr_conv2d_fp8": (i32, [P(ConvDesc), P(Fp8Desc), vp]),
     "sslcr_conv2d_fp8_partial_rows": (i32, [P(ConvDesc)]),
     "sslcr_pack_conv_fp8": (i32, [P(PackFp8Desc), vp]),

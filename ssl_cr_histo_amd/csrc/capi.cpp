@@ -46,6 +46,15 @@ int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream) {
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d) { return d ? conv_partials_rows(*d) : -1; }
 int sslcr_conv2d_segments_ok(int dtype, const sslcr_conv_desc* d) { return (d && (dtype == DT_F32 || dtype == DT_BF16) && conv_segments_ok(dtype, *d)) ? 1 : 0; }
 const char* sslcr_conv2d_kernel_name(int dtype, const sslcr_conv_desc* d) { return d ? conv_kernel_name(dtype, *d) : ""; }
+int sslcr_conv2d_s2_pair_ok(int dtype, const sslcr_conv_desc* c1, const sslcr_conv_desc* ds) {
+  return (c1 && ds && conv_s2_pair_ok(dtype, *c1, *ds)) ? 1 : 0;
+}
+int sslcr_conv2d_s2_pair(int dtype, const sslcr_conv_desc* c1, const sslcr_conv_desc* ds, void* stream) {
+  DT_OK(dtype);
+  NEED(c1 && ds && c1->x && c1->w && c1->y && ds->w && ds->y, "null tensor");
+  NEED(conv_s2_pair_ok(dtype, *c1, *ds), "pair not served (sslcr_conv2d_s2_pair_ok)");
+  return check(launch_conv_s2(*c1, ds, (hipStream_t)stream), "conv2d_s2_pair");
+}
 
 int sslcr_conv2d_fp8(const sslcr_conv_desc* d, const sslcr_fp8_desc* q, void* stream) {
   NEED(d && q && d->x && d->y && q->w8 && q->w_dequant, "null tensor");

@@ -53,6 +53,12 @@ int conv_dma_bp(int dtype, const ConvArgs& a);
 int conv_dma_rows(const ConvArgs& a, int bp);
 hipError_t launch_conv_dma(int dtype, const ConvArgs& a, int bp, hipStream_t st);
 const char* conv_dma_name(int dtype, int bp);
+// conv_s2.hip: 3x3 / 2 on 16x16 output tiles by plane-gathering LDS DMA, optionally with the 1x1 / 2 projection of the same input (bf16)
+bool conv_s2_ok(int dtype, const ConvArgs& a);
+bool conv_s2_pair_ok(int dtype, const ConvArgs& a, const ConvArgs& d);
+int conv_s2_rows(const ConvArgs& a);
+hipError_t launch_conv_s2(const ConvArgs& a, const ConvArgs* d, hipStream_t st);
+const char* conv_s2_name(const ConvArgs& a, bool pair);
 // conv_fp8.hip
 int conv_fp8_mode(const ConvArgs& a);
 int conv_fp8_rows(const ConvArgs& a);

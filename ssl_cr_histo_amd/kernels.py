@@ -78,6 +78,33 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
     return (y, stats) if want_stats else y
 
 
+def conv2d_s2_pair(x, w3, w1, *, bias3=None, bias1=None, relu3=False, want_stats=False):
+    """a downsampling BasicBlock's conv1 (3x3 / 2 / pad 1, w3 [K,3,3,C]) and projection (1x1 / 2, w1 [K,1,1,C]) of ONE input in one
+    launch (sslcr_conv2d_s2_pair) -> (y3, yd) or (y3, yd, stats3, statsd)"""
+    _chk(x, w3, w1, bias3, bias1)
+    dt = _dt(x)
+    N, H, W, C = x.shape
+    K = w3.shape[0]
+    assert w3.shape == (K, 3, 3, C) and w1.shape == (K, 1, 1, C)
+    PH, PW = H // 2, W // 2
+    y3 = torch.empty((N, PH, PW, K), dtype=x.dtype, device=x.device)
+    yd = torch.empty_like(y3)
+    d3 = L.ConvDesc(L.ptr(x), L.ptr(w3), L.ptr(y3), None, None, L.ptr(bias3), None, None,
+                    N, H, W, C, K, 3, 3, 2, 1, PH, PW, PH, PW, 1, 0, 0, int(relu3), 0, 0, 0, 0, 0)
+    d1 = L.ConvDesc(L.ptr(x), L.ptr(w1), L.ptr(yd), None, None, L.ptr(bias1), None, None,
+                    N, H, W, C, K, 1, 1, 2, 0, PH, PW, PH, PW, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+    s3 = sd = None
+    if want_stats:
+        rows = L.lib().sslcr_conv2d_partial_rows(d3)
+        s3 = torch.full((rows, 2, K), float("nan"), dtype=torch.float32, device=x.device)
+        sd = torch.full((rows, 2, K), float("nan"), dtype=torch.float32, device=x.device)
+        d3.stats, d1.stats = L.ptr(s3), L.ptr(sd)
+    if not L.lib().sslcr_conv2d_s2_pair_ok(dt, d3, d1):
+        raise L.SslcrError("conv2d_s2_pair: not served")
+    L.check(L.lib().sslcr_conv2d_s2_pair(dt, d3, d1, L.stream_ptr()))
+    return (y3, yd, s3, sd) if want_stats else (y3, yd)
+
+
 def pack_conv_fp8(w_kcrs, *, bn=None, eps=1e-5):
     """PyTorch [K,C,3,3] fp32 -> (w8 [K,3,3,C] uint8 = OCP e4m3 bits, w_dequant [K] fp32, bias [K] | None): per-output-channel
     power-of-two scale (amax -> (224, 448]); bn = (gamma, beta, running_mean, running_var) folds eval-mode BatchNorm."""

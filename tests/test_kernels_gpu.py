@@ -80,6 +80,10 @@ CONV_CASES = [
     (10, 30, 34, 64, 128, 3, 2, 1),    # all-DMA gather conv: stride 2, ragged M = 2550, 128x128 tiles
     (10, 30, 34, 128, 64, 3, 2, 1),    # all-DMA gather conv: 256x64 tiles, 2 channel slabs
     (9, 32, 32, 64, 128, 1, 2, 0),     # all-DMA gather conv: 1x1/2 projection
+    (6, 64, 64, 64, 128, 3, 2, 1),     # plane-gather stride-2 conv (bf16; fp32 stays on the gather kernel): 4 tiles per image, one slab
+    (9, 32, 32, 128, 256, 3, 2, 1),    # ... one tile per image, 2 slabs, 2 kout blocks on 18 workgroups (kout-block-fastest walk)
+    (70, 64, 64, 64, 128, 3, 2, 1),    # ... 280 items on 256 workgroups: a workgroup walks into a second item
+    (6, 32, 64, 256, 384, 3, 2, 1),    # ... 4 slabs, 3 kout blocks (kout-block-major walk), 2 tiles per image side by side
 ]
 
 
@@ -97,6 +101,8 @@ def test_conv_fwd_raw_stats(case, dtype):
               (4, 8, 8, 512, 512, 3, 1, 1): ", 8>", (320, 8, 8, 64, 512, 3, 1, 1): ", 8>"}.get(case)   # conv3x3_h16<..., 8>: four-image tiles
     if expect:
         assert expect in K.last_conv_kernel, K.last_conv_kernel
+    if case[1] % 32 == 0 and case[2] % 32 == 0 and Rr == 3 and stride == 2 and Ko % 128 == 0:
+        assert ("conv_s2_kernel<false, false>" if dtype == 1 else "conv_dma_kernel<float") in K.last_conv_kernel, K.last_conv_kernel
     if case == (70, 32, 32, 64, 64, 3, 1, 1) and dtype == 1:      # 280 tiles on 256 workgroups: the resident-filter walk
         assert "conv3x3_pp64_kernel<false, 0>" in K.last_conv_kernel, K.last_conv_kernel
     want = R.conv_fwd(x, w, stride, pad)
@@ -105,6 +111,37 @@ def test_conv_fwd_raw_stats(case, dtype):
     st = stats.double().sum(0).cpu()
     close(st[0], s, 2e-4 if dtype == 0 else 2e-3, "sum")
     close(st[1], ss, 2e-4 if dtype == 0 else 2e-3, "sumsq")
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("shape", [(6, 64, 64, 64, 128), (9, 32, 32, 128, 256), (70, 64, 64, 64, 128), (6, 32, 64, 256, 384), (130, 32, 32, 128, 256)])
+def test_conv_s2_pair(shape, mode):
+    """a downsampling block's conv1 (3x3 / 2) and 1x1 / 2 projection of one input in ONE launch (sslcr_conv2d_s2_pair, bf16): raw
+    outputs + BatchNorm partial rows (train forward) and bias (+ ReLU on conv1) with the BatchNorm folded (eval forward)"""
+    K = _k()
+    N, H, W, C, Ko = shape
+    x = q(rnd(41, (N, H, W, C)), 1)
+    w3 = q(rnd(42, (Ko, 3, 3, C), 0.05), 1)
+    w1 = q(rnd(43, (Ko, 1, 1, C), 0.1), 1)
+    if mode == "train":
+        y3, yd, s3, sd = K.conv2d_s2_pair(to_dev(x, 1), to_dev(w3, 1), to_dev(w1, 1), want_stats=True)
+        for y, st, w, (r, pad) in ((y3, s3, w3, (3, 1)), (yd, sd, w1, (1, 0))):
+            want = R.conv_fwd(x, w, 2, pad)
+            close(y, want, TOL[1], f"raw {r}x{r}")
+            s, ss = R.channel_stats(want)
+            tot = st.double().sum(0).cpu()
+            close(tot[0], s, 2e-3, "sum")
+            close(tot[1], ss, 2e-3, "sumsq")
+    else:
+        b3, b1 = rnd(44, (Ko,)), rnd(45, (Ko,))
+        y3, yd = K.conv2d_s2_pair(to_dev(x, 1), to_dev(w3, 1), to_dev(w1, 1), bias3=b3.to(DEV), bias1=b1.to(DEV), relu3=True)
+        close(y3, R.conv_fwd(x, w3, 2, 1, bias=b3, relu=True), TOL[1], "eval 3x3")
+        close(yd, R.conv_fwd(x, w1, 2, 0, bias=b1), TOL[1], "eval 1x1")
+    # the single-conv instance through the ordinary entry point gives the same bits as the pair's first accumulator set
+    if mode == "eval":
+        y3s = K.conv2d(to_dev(x, 1), to_dev(w3, 1), 2, 1, bias=b3.to(DEV), relu=True)
+        assert "conv_s2_kernel<false, true>" in K.last_conv_kernel, K.last_conv_kernel
+        assert torch.equal(y3s, y3)
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
