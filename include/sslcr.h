@@ -229,6 +229,12 @@ typedef struct sslcr_bn_bwd_desc {
   const uint8_t* yact_bits;   /* instead of yact (bf16 only): its sign mask as written by sslcr_bn_act (ybits) -- g = dy where the bit is
                                  set, 0 elsewhere: the same g, bit for bit, for 1/16 of yact's bytes */
 } sslcr_bn_bwd_desc;
+/* ABI note (library version >= 4): sslcr_bn_bwd_reduce OVERWRITES d->sums (until version 3 it accumulated into a buffer the caller had
+ * zeroed) -- several reduce calls into one sums buffer keep only the last one; add them on the caller's side.  The reduce pass and the
+ * weight-gradient entry points (sslcr_conv2d_wgrad, sslcr_stem_wgrad*) keep per-stream scratch for their ordered folds: the first call
+ * on a stream (and any call that needs more than before) allocates with hipMalloc / hipStreamSynchronize INSIDE the call, so these
+ * entry points must not be issued under hipStreamBeginCapture unless an earlier un-captured call on that stream has sized the scratch.
+ * The scratch is released by sslcr_destroy. */
 int sslcr_bn_bwd_reduce(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_bwd_apply(int dtype, const sslcr_bn_bwd_desc* d, void* stream);
 int sslcr_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, void* stream);

@@ -281,6 +281,9 @@ int conv_dma_bp(int dtype, const ConvArgs& a) {
   if (a.C % ce != 0 || a.K % 64 != 0 || a.R * a.S > 31) return 0;
   const long M = (long)a.N * a.PH * a.PW;
   if (M < 2048) return 0;                        // tiny problems stay on the 64x64-tile kernel
+  // the input's buffer resource starts at a workgroup's first image and its lane offsets are 32-bit: the images one pixel block can
+  // span (256 pixels at most, plus the partial images at both ends) must stay below 2 GB
+  if (((long)(256 / (a.PH * a.PW)) + 2) * a.H * a.W * a.C * (dtype == DT_BF16 ? 2 : 4) >= (1l << 31)) return 0;
   return a.K % 128 == 0 ? 128 : 256;
 }
 int conv_dma_rows(const ConvArgs& a, int bp) {

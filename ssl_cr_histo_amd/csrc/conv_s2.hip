@@ -16,17 +16,16 @@
 //   * a STAGE is one plane of one slab (37 KB, 2-4 taps); three plane buffers roll: stage S computes on buffer S % 3 while stage
 //     S + 1 has landed and stage S + 2 is in flight -- no stage-end halo swap, no staging registers, two stages (>= 4 taps) of lead;
 //   * weights go through a ring of three single-tap slots (16 KB each), one tap of lead;
-//   * ONE bare s_barrier per tap, at its start: it publishes the next tap's weights (and, at a stage's last tap, the next stage's
-//     plane -- the first fragments of a tap are read one k-step ahead, before its barrier) and frees the previous tap's slot (at a
-//     stage's first tap, the previous stage's buffer), whose reads fed MFMAs that have been issued;
-//   * s_waitcnt vmcnt retires IN ORDER, so the two streams are issued by different waves: waves 4-7 gather plane pieces and wait
-//     for a plane one to three taps after its last piece, waves 0-3 stream weight taps and wait one tap later; neither wait covers
-//     the other stream's younger requests.  A DMA instruction costs its wave 100-200 cycles of issue (measured: the same walk
-//     without any DMA runs 1617 cycles per tap, with all of them issued by every wave right behind the barrier 2290), so the roles
-//     are also the PHASES of a SIMD's wave pair: a weight wave issues its four pieces first and then its 32 MFMAs, the plane wave
-//     of the same SIMD runs its 32 MFMAs first and issues its two to five pieces behind them -- one feeds the matrix pipe while
-//     the other sits in its DMA issue.  An item's output stores are issued BEHIND the weight request they could delay, and the one
-//     wait in front of them is counted (vmcnt(16)), so no wave waits out a write round trip.
+//   * ONE bare s_barrier per tap, in the middle of it (between its two 32-channel k-steps): it publishes the next tap's weights
+//     (and, at a stage's last tap, the next stage's plane) and frees the previous tap's slot (at a stage's first tap, the previous
+//     stage's buffer) -- whose last reads fed the MFMAs of the step before the barrier;
+//   * a DMA instruction costs its wave 100-500 cycles of issue (measured: the same walk without any DMA runs 1617 cycles per tap;
+//     with four waves gathering planes and four streaming weights 2620-2860, with every wave issuing its share of both 2290), so all
+//     eight waves issue, two weight pieces and one to three plane pieces per tap each, and the waves of a SIMD pair issue their plane
+//     pieces in different phases -- waves 0-3 in front of their 32 MFMAs, waves 4-7 behind theirs;
+//   * s_waitcnt vmcnt retires IN ORDER: a wave's requests are ordered (weights of tap t + 2, then plane pieces) and every barrier's
+//     wait is counted -- the plane pieces of the previous tap may stay outstanding, so a weight tap has one tap of lead and a plane
+//     piece two; an item's output stores are issued behind the requests they could delay and counted too (vmcnt(n + 16)).
 // 8 waves, wave (wp, wk) = 4 output rows x 64 kouts (TK = TP = 4), two accumulator sets (conv1, projection) = 128 registers,
 // fragments double-buffered across the barriers.  Output stage: pack + store (+ BatchNorm partial sums by the row16_fold16 tree)
 // for the train forward, bias (+ ReLU) for the eval forward with the BatchNorm folded (EVAL instance).  bf16 only; the fp32 parity
@@ -66,8 +65,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, li = lane & 15;
   const int wp = wave & 3, wk = wave >> 2;
-  const bool hrole = wave >= 4;               // waves 4-7 gather plane pieces (behind their MFMAs), waves 0-3 stream weight taps (in front of theirs)
-  const int rw = wave & 3;                    // index within the role
+  const bool late = wave >= 4;                // waves 4-7 issue their plane pieces BEHIND their MFMAs, waves 0-3 in front
   const int OH = a.PH, OW = a.PW;
   const int tiles_w = OW / 16, tiles_h = OH / 16;
   const int G = gridDim.x;
@@ -153,7 +151,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
     const int rr = w * 8 + (lane >> 3);
     return (wperm_inv4(rr) * rowbytes + (((lane & 7) ^ (rr & 7)) << 4));
   };
-  const int wsrc0 = wsrc_of(rw, 9 * a.C * (int)sizeof(T)), wsrc0d = wsrc_of(rw, a.C * (int)sizeof(T));     // the four weight waves' (pieces rw, rw + 4, ..)
+  const int wsrc0 = wsrc_of(wave, 9 * a.C * (int)sizeof(T)), wsrc0d = wsrc_of(wave, a.C * (int)sizeof(T));     // pieces wave, wave + 8
   LdsDma wdma, wdmad;
   wdma.init(a.w, 0x7fffffffu);
   wdmad.init(PAIR ? d.w : a.w, 0x7fffffffu);
@@ -228,18 +226,15 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
   Geo cur = geom(first);
   hc.item = first; hc.slab = 0; hc.plane = 1; hc.valid = true; hc.q = cur;
   wc.item = first; wc.slab = 0; wc.tap = 1; wc.valid = true; wc.k0 = cur.k0;
-  {
-    const int p0 = wsrc_of(wave, 9 * a.C * (int)sizeof(T)), p0d = wsrc_of(wave, a.C * (int)sizeof(T));     // all eight waves share the fill
-    issue_w(cur.k0, 0, 0, 0, 8, wave, p0, p0d);
-    issue_w(cur.k0, 0, 1, 1, 8, wave, p0, p0d);
-    issue_halo(cur, 0, 0, 0, 8, wave, 0, 5);
-    issue_halo(cur, 0, 1, 1, 8, wave, 0, 5);
-  }
+  issue_w(cur.k0, 0, 0, 0, 8, wave, wsrc0, wsrc0d);
+  issue_w(cur.k0, 0, 1, 1, 8, wave, wsrc0, wsrc0d);
+  issue_halo(cur, 0, 0, 0, 8, wave, 0, 5);
+  issue_halo(cur, 0, 1, 1, 8, wave, 0, 5);
   S2_VMCNT(0);
   __syncthreads();
 
   int hb = 0, ws = 0;                          // plane buffer of the current stage, weight slot of the current tap
-  bool h_ok = false;                           // the plane wave's latest site issued its pieces (uniform): the counted younger requests exist
+  bool prev_ok = false;                        // the previous tap's site issued its plane pieces (uniform): its count may stay outstanding
   bool after_epi = false;                      // the output stores of the previous item are the youngest requests of this wave
   auto set_a = [&](int slot) {
     const int o = slot * WS, dlt = o - a_off;
@@ -280,45 +275,44 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
     else if ((n) == 11) S2_VMCNT(11); else if ((n) == 12) S2_VMCNT(12); else if ((n) == 16) S2_VMCNT(16); else if ((n) == 17) S2_VMCNT(17); \
     else if ((n) == 18) S2_VMCNT(18); else if ((n) == 19) S2_VMCNT(19); else if ((n) == 20) S2_VMCNT(20); else S2_VMCNT(0);       \
   } while (0)
-  // One tap: barrier, [weight waves: the four pieces of the tap two ahead], two k-steps of 16 MFMAs (the second one reads the NEXT
-  // tap's first fragments ahead), [plane waves: pieces I0 .. I0 + NI - 1 of the plane two stages ahead, TPL].  HWAIT >= 0: this
-  // barrier is the deadline of the next stage's plane (LAST tap of a stage) -- the plane waves let their HWAIT youngest requests (pieces
-  // of the plane after it, all issued if h_ok) stay outstanding.  HADV: first tap of a stage, the plane cursor moves on.
-#define S2_TAP(DR, DC, P17, SET, LAST, HWAIT, HADV, TPL, I0, NI, NDR, NDC, NP17, ITEM_FIRST)                \
+  // One tap = two k-steps with the barrier BETWEEN them (at the tap boundary it measured 4-10 % slower: the second k-step's MFMAs are
+  // what runs while the partner wave issues).  Behind the barrier every wave requests its two pieces of the weight tap two ahead,
+  // then pieces I0 .. I0 + HP - 1 (piece i = plane group 8 i + wave) of the plane two stages ahead (TPL) -- waves 0-3 at once, waves
+  // 4-7 behind the second k-step's MFMAs, so that on every SIMD one wave feeds the matrix pipe while the other sits in its DMA issue.
+  // A wave's requests retire in order: the wait lets the NPREV plane pieces every wave issued behind the previous barrier stay
+  // outstanding -- the next tap's weights and every plane piece requested two barriers ago or earlier have landed.  So a plane's
+  // pieces go out at least two barriers before the one that needs them (in the last tap of the stage before).
+  // FIRST / LAST: position in the stage (FIRST moves the plane cursor on, LAST rotates the plane buffer); N*: the next tap's fragments.
+#define S2_TAP(DR, DC, P17, SET, FIRST, LAST, NPREV, TPL, I0, HP, NDR, NDC, NP17, ITEM_FIRST)               \
   do {                                                                                                      \
+    S2_FRAGS(1, 1, DR, DC, P17);                                                                            \
+    S2_MFMA(0, SET);                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
     {                                                                                                       \
       S2_T(tb0);                                                                                            \
-      if (hrole) {                                                                                          \
-        if ((HWAIT) >= 0) { if (h_ok) S2_WAIT(HWAIT); else S2_VMCNT(0); }                                   \
-      } else {                                                                                              \
-        if ((ITEM_FIRST) && after_epi) S2_WAIT(NST); else S2_VMCNT(0);                                      \
-      }                                                                                                     \
+      if (!prev_ok) S2_VMCNT(0);                                                                            \
+      else if ((ITEM_FIRST) && after_epi) S2_WAIT((NPREV) + NST);                                           \
+      else S2_WAIT(NPREV);                                                                                  \
       S2_T(tb1);                                                                                            \
       S2_BARRIER();                                                                                         \
       S2_T(tb2);                                                                                            \
       S2_ACC(0, tb1 - tb0); S2_ACC(1, tb2 - tb1);                                                           \
     }                                                                                                       \
     if (ITEM_FIRST) after_epi = false;                                                                      \
-    if (!hrole) {                                                                                           \
-      wc_next();                                                                                            \
-      if (wc.valid) issue_w(wc.k0, wc.slab, wc.tap, ws == 0 ? 2 : ws - 1, 4, rw, wsrc0, wsrc0d);            \
-    }                                                                                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
-    S2_FRAGS(1, 1, DR, DC, P17);                                                                            \
-    S2_MFMA(0, SET);                                                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    wc_next();                                                                                              \
+    if (wc.valid) issue_w(wc.k0, wc.slab, wc.tap, ws == 0 ? 2 : ws - 1, 8, wave, wsrc0, wsrc0d);            \
+    if (FIRST) hc_next();                                                                                   \
+    prev_ok = hc.valid;                                                                                     \
     const int hb_req = hb == 0 ? 2 : hb - 1;                                                                \
+    if (!late && hc.valid && (HP) > 0) issue_halo(hc.q, hc.slab, TPL, hb_req, 8, wave, I0, HP);             \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
     ws = ws == 2 ? 0 : ws + 1;                                                                              \
     set_a(ws);                                                                                              \
     if (LAST) { hb = hb == 2 ? 0 : hb + 1; set_b(hb, NP17); }                                               \
     S2_FRAGS(0, 0, NDR, NDC, NP17);                                                                         \
     S2_MFMA(1, SET);                                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if (hrole) {                                                                                            \
-      if (HADV) hc_next();                                                                                  \
-      h_ok = hc.valid;                                                                                      \
-      if (hc.valid && (NI) > 0) issue_halo(hc.q, hc.slab, TPL, hb_req, 4, rw, I0, NI);                      \
-    }                                                                                                       \
+    if (late && hc.valid && (HP) > 0) issue_halo(hc.q, hc.slab, TPL, hb_req, 8, wave, I0, HP);              \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
   } while (0)
 
@@ -330,27 +324,26 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
   const unsigned long long s2_begin = __builtin_readcyclecounter();
 #endif
   S2_FRAGS(0, 0, 0, 0, true);
-  // Plane pieces per tap (a plane wave issues pieces rw, rw + 4, ... of a plane's 37 / 34 / 34 / 32: 10 / 9 / 9 / 8 at most) and the
-  // deadlines: a stage's plane must have landed at the barrier of the PREVIOUS stage's last tap.  HWAIT there = the pieces every
-  // plane wave has issued since for the plane after it.
+  // Plane pieces per tap (a plane is 37 / 34 / 34 / 32 pieces = at most 5 per wave).  NPREV of a tap = the number of i in the
+  // PREVIOUS tap's range with 8 i + 7 < pieces (what every wave issued there).
+  constexpr int NP0 = PAIR ? 1 : 4;            // ... of a slab's last tap, seen by the next slab's first
   for (;;) {
-    //     DR DC P17    SET LAST   HWAIT HADV TPL I0 NI  next: DR DC P17
-    S2_TAP(0, 0, true, 0, false, -1, true, 2, 0, 3, 0, 1, true, true);          // OO (0,0)   EO pieces 0-2
-    S2_TAP(0, 1, true, 0, false, -1, false, 2, 3, 2, 1, 0, true, false);        // OO (0,2)             3-4
-    S2_TAP(1, 0, true, 0, false, -1, false, 2, 5, 2, 1, 1, true, false);        // OO (2,0)             5-6
-    S2_TAP(1, 1, true, 0, true, 7, false, 2, 7, 2, 0, 0, false, false);         // OO (2,2)             7-8    deadline of OE (younger: EO 0-6)
-    S2_TAP(0, 0, false, 0, false, -1, true, 3, 0, 4, 1, 0, false, false);       // OE (0,1)   EE pieces 0-3
-    S2_TAP(1, 0, false, 0, true, 4, false, 3, 4, 4, 0, 0, true, false);         // OE (2,1)             4-7    deadline of EO (younger: EE 0-3)
+    //     DR DC P17    SET FIRST  LAST   NPREV TPL I0 HP  next: DR DC P17
+    S2_TAP(0, 0, true, 0, true, false, NP0, 2, 0, 2, 0, 1, true, true);         // OO (0,0)   EO pieces 0-1
+    S2_TAP(0, 1, true, 0, false, false, 2, 2, 2, 1, 1, 0, true, false);         // OO (0,2)             2
+    S2_TAP(1, 0, true, 0, false, false, 1, 2, 3, 1, 1, 1, true, false);         // OO (2,0)             3
+    S2_TAP(1, 1, true, 0, false, true, 1, 2, 4, 1, 0, 0, false, false);         // OO (2,2)             4 (groups 32-33)
+    S2_TAP(0, 0, false, 0, true, false, 0, 3, 0, 2, 1, 0, false, false);        // OE (0,1)   EE pieces 0-1
+    S2_TAP(1, 0, false, 0, false, true, 2, 3, 2, 2, 0, 0, true, false);         // OE (2,1)             2-3
     if constexpr (PAIR) {
-      S2_TAP(0, 0, true, 0, false, -1, true, 0, 0, 5, 0, 1, true, false);       // EO (1,0)   next OO pieces 0-4
-      S2_TAP(0, 1, true, 0, true, 5, false, 0, 5, 5, 0, 0, false, false);       // EO (1,2)             5-9    deadline of EE (younger: OO 0-4)
-      S2_TAP(0, 0, false, 0, false, -1, true, 1, 0, 5, 0, 0, false, false);     // EE (1,1)   next OE pieces 0-4
-      S2_TAP(0, 0, false, 1, true, 5, false, 1, 5, 4, 0, 0, true, false);       // EE projection        5-8    deadline of the next OO (younger: OE 0-4)
+      S2_TAP(0, 0, true, 0, true, false, 2, 0, 0, 3, 0, 1, true, false);        // EO (1,0)   next OO pieces 0-2
+      S2_TAP(0, 1, true, 0, false, true, 3, 0, 3, 2, 0, 0, false, false);       // EO (1,2)             3-4
+      S2_TAP(0, 0, false, 0, true, false, 1, 1, 0, 3, 0, 0, false, false);      // EE (1,1)   next OE pieces 0-2
+      S2_TAP(0, 0, false, 1, false, true, 3, 1, 3, 2, 0, 0, true, false);       // EE projection        3-4
     } else {
-      // (one tap in the EE stage: the next OO plane is due one tap after its request opens, so all of it goes out at once)
-      S2_TAP(0, 0, true, 0, false, -1, true, 0, 0, 10, 0, 1, true, false);      // EO (1,0)   next OO pieces 0-9
-      S2_TAP(0, 1, true, 0, true, 9, false, 0, 0, 0, 0, 0, false, false);       // EO (1,2)                    deadline of EE (younger: OO 0-8)
-      S2_TAP(0, 0, false, 0, true, 0, true, 1, 0, 9, 0, 0, true, false);        // EE (1,1)   next OE pieces 0-8; deadline of the next OO
+      S2_TAP(0, 0, true, 0, true, false, 2, 0, 0, 5, 0, 1, true, false);        // EO (1,0)   next OO pieces 0-4 (the EE stage is one tap)
+      S2_TAP(0, 1, true, 0, false, true, 4, 0, 0, 0, 0, 0, false, false);       // EO (1,2)
+      S2_TAP(0, 0, false, 0, true, true, 0, 1, 0, 5, 0, 0, true, false);        // EE (1,1)   next OE pieces 0-4
     }
     if (++slab < nslabs) continue;
     slab = 0;

@@ -322,6 +322,22 @@ hipError_t prof_conv(sslcr_ctx* c, int dt, const ConvArgs& a, hipStream_t st) {
   c->prof.rec[0].push_back(r);
   return e;
 }
+// a downsampling block's conv1 (3x3 / 2) and 1x1 / 2 projection of one input in one launch (conv_s2.hip)
+hipError_t prof_conv_pair(sslcr_ctx* c, const ConvArgs& a, const ConvArgs& d, hipStream_t st) {
+  if (!c->prof.on) return launch_conv_s2(a, &d, st);
+  ProfRec r;
+  r.e0 = c->prof.get(); r.e1 = c->prof.get();
+  const double es = c->esz();
+  const double M = (double)a.N * a.PH * a.PW, src = (double)a.N * a.H * a.W;
+  r.flops = 2.0 * M * a.K * a.C * 10.0;
+  r.bytes = (src * a.C + (double)a.K * 10.0 * a.C + 2.0 * M * a.K) * es;
+  r.name = conv_s2_name(a, true);
+  (void)hipEventRecord(r.e0, st);
+  hipError_t e = launch_conv_s2(a, &d, st);
+  (void)hipEventRecord(r.e1, st);
+  c->prof.rec[0].push_back(r);
+  return e;
+}
 inline bool fp8_layer(const sslcr_ctx* c, const ConvL& L) {
   return c->fp8 && L.k == 3 && L.stride == 1 && L.cin % 128 == 0 && L.cout % 128 == 0;
 }
@@ -686,10 +702,33 @@ int forward_blocks(sslcr_net* n, PassState& ps, int N, int H, int W, int replay,
     float* part; int rows;
     ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fwd, ps.blk[i].raw1, NT, xh, xw);
     if (segs) a1.seg_images = N;
-    TRYI(ensure_partials(c, a1, &part, &rows, !segs && use_fp8(c, B.c1, a1)));
-    a1.stats = part;
-    TRY(segs ? prof_conv(c, dt, a1, st) : prof_conv_fwd(c, dt, a1, B.c1, false, st));
-    TRYI(finalize_bn(n, B.b1, part, rows, cnt, ps.bn[B.b1.bidx], replay, st, nseg, seg_stride));
+    // a downsampling block's conv1 and projection read the same input: one launch where the plane-gather kernel serves the pair
+    // (both sets of statistics rows, the projection's BatchNorm finalized before conv2 reuses the rows buffer)
+    ConvArgs ad;
+    bool paired = false;
+    if (B.has_ds) {
+      ad = conv_args(B.ds, X, B.ds.w_fwd, ps.blk[i].rawd, NT, xh, xw);
+      if (segs) ad.seg_images = N;
+      ConvArgs t1 = a1, td = ad;
+      t1.stats = td.stats = c->zeros;                // (any non-null pointer: the predicate looks at the mode only)
+      paired = !use_fp8(c, B.c1, a1) && conv_s2_pair_ok(dt, t1, td);
+    }
+    if (paired) {
+      rows = conv_partials_rows(a1);
+      const size_t rb = (size_t)rows * 2 * a1.K * sizeof(float);
+      TRYI(c->partials.ensure(2 * rb));
+      part = (float*)c->partials.p;
+      a1.stats = part;
+      ad.stats = (float*)((char*)c->partials.p + rb);
+      TRY(prof_conv_pair(c, a1, ad, st));
+      TRYI(finalize_bn(n, B.b1, a1.stats, rows, cnt, ps.bn[B.b1.bidx], replay, st, nseg, seg_stride));
+      TRYI(finalize_bn(n, B.bd, ad.stats, rows, cnt, ps.bn[B.bd.bidx], replay, st, nseg, seg_stride));
+    } else {
+      TRYI(ensure_partials(c, a1, &part, &rows, !segs && use_fp8(c, B.c1, a1)));
+      a1.stats = part;
+      TRY(segs ? prof_conv(c, dt, a1, st) : prof_conv_fwd(c, dt, a1, B.c1, false, st));
+      TRYI(finalize_bn(n, B.b1, part, rows, cnt, ps.bn[B.b1.bidx], replay, st, nseg, seg_stride));
+    }
     ConvArgs a2 = conv_args(B.c2, ps.blk[i].raw1, B.c2.w_fwd, ps.blk[i].raw2, NT, oh, ow);
     a2.in_scale = ps.bn[B.b1.bidx].scale; a2.in_shift = ps.bn[B.b1.bidx].shift; a2.in_relu = 1;
     if (segs) { a2.seg_images = N; a2.seg_stride = seg_stride; }
@@ -704,12 +743,12 @@ int forward_blocks(sslcr_net* n, PassState& ps, int N, int H, int W, int replay,
     if (segs) { e.nseg = nseg; e.seg_stride = seg_stride; }
     if (n->ybits_ok && ybits_on(c)) e.ybits = ps.blk[i].ybits;
     if (B.has_ds) {
-      ConvArgs ad = conv_args(B.ds, X, B.ds.w_fwd, ps.blk[i].rawd, NT, xh, xw);
-      if (segs) ad.seg_images = N;
-      TRYI(ensure_partials(c, ad, &part, &rows));
-      ad.stats = part;
-      TRY(prof_conv(c, dt, ad, st));
-      TRYI(finalize_bn(n, B.bd, part, rows, cnt, ps.bn[B.bd.bidx], replay, st, nseg, seg_stride));
+      if (!paired) {
+        TRYI(ensure_partials(c, ad, &part, &rows));
+        ad.stats = part;
+        TRY(prof_conv(c, dt, ad, st));
+        TRYI(finalize_bn(n, B.bd, part, rows, cnt, ps.bn[B.bd.bidx], replay, st, nseg, seg_stride));
+      }
       e.res = ps.blk[i].rawd; e.rscale = ps.bn[B.bd.bidx].scale; e.rshift = ps.bn[B.bd.bidx].shift;
     } else {
       e.res = X;
@@ -817,13 +856,19 @@ int backbone_forward_eval(sslcr_net* n, const void* const* xs, int npass, int in
     const int oh = d.lh[i], ow = d.lw[i];
     ConvArgs a1 = conv_args(B.c1, X, B.c1.w_fold, t1, NT, xh, xw);
     a1.bias = B.c1.b_fold; a1.relu = 1;
-    TRY(prof_conv_fwd(c, dt, a1, B.c1, true, st));
     const void* res = X;
     if (B.has_ds) {
       ConvArgs ad = conv_args(B.ds, X, B.ds.w_fold, td, NT, xh, xw);
       ad.bias = B.ds.b_fold;
-      TRY(prof_conv(c, dt,ad, st));
+      if (!use_fp8(c, B.c1, a1) && conv_s2_pair_ok(dt, a1, ad)) {      // conv1 and the projection in one launch
+        TRY(prof_conv_pair(c, a1, ad, st));
+      } else {
+        TRY(prof_conv_fwd(c, dt, a1, B.c1, true, st));
+        TRY(prof_conv(c, dt,ad, st));
+      }
       res = td;
+    } else {
+      TRY(prof_conv_fwd(c, dt, a1, B.c1, true, st));
     }
     ConvArgs a2 = conv_args(B.c2, t1, B.c2.w_fold, Y, NT, oh, ow);
     a2.bias = B.c2.b_fold; a2.residual = res; a2.relu = 1;
@@ -1505,6 +1550,7 @@ int sslcr_destroy(sslcr_ctx* c) {
     (void)hipEventDestroy(c->ev_done);
   }
   c->scratch.release(); c->partials.release(); c->small.release(); c->bn_ring.release();
+  stream_scratch_release();          // the per-stream fold scratch of the weight-gradient / BatchNorm-backward launches
   delete c;
   return 0;
 }

@@ -73,6 +73,7 @@ int wgrad_halo_tw(const WgradArgs& a);
 // the weight-gradient kernels (wgrad_fold_kernel) and the per-workgroup rows of the BatchNorm-backward reduce pass (bn_bwd_sums_kernel);
 // the launches that fold them, wgrad_halo.hip
 void* stream_scratch(hipStream_t st, size_t bytes);
+void stream_scratch_release();      // frees every stream's scratch (sslcr_destroy, after a device synchronise)
 hipError_t launch_wgrad_fold(const void* slabs, float* dw, int C, int gx, int gy, int splits, int taps, int kh_n, hipStream_t st);
 hipError_t launch_stem_wgrad_fold(const void* slabs, float* dw, int nwg, hipStream_t st);
 hipError_t launch_wgrad_halo(int dtype, const WgradArgs& a, int tw, hipStream_t st);

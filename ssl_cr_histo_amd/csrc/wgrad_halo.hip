@@ -392,14 +392,26 @@ hipError_t launch_stem_wgrad_fold(const void* slabs, float* dw, int nwg, hipStre
 // One entry per stream, 64 entries, least-recently-used eviction (logged once: it costs a device synchronise): a 65th stream (virtual-rank tests create a stream per context
 // and drop it) takes over the oldest entry after a device synchronise -- never a silent fall-back to the atomic path, whose
 // summation order differs -- and an evicted or destroyed stream's slab is freed instead of leaking.
+namespace {
+struct Slab { hipStream_t st; void* p; size_t cap; unsigned long long used; };
+constexpr int NSLAB = 64;
+Slab g_slabs[NSLAB];
+int g_nslabs = 0;
+unsigned long long g_slab_tick = 0;
+std::mutex g_slab_mu;                            // host threads driving different streams
+}  // namespace
+// sslcr_destroy: every stream's slab is freed (the device has been synchronised; a later launch allocates again)
+void stream_scratch_release() {
+  std::lock_guard<std::mutex> lock(g_slab_mu);
+  for (int i = 0; i < g_nslabs; ++i)
+    if (g_slabs[i].p) (void)hipFree(g_slabs[i].p);
+  g_nslabs = 0;
+}
 void* stream_scratch(hipStream_t st, size_t bytes) {
-  struct Slab { hipStream_t st; void* p; size_t cap; unsigned long long used; };
-  constexpr int NSLAB = 64;
-  static Slab slabs[NSLAB];
-  static int n = 0;
-  static unsigned long long tick = 0;
-  static std::mutex mu;                          // host threads driving different streams
-  std::lock_guard<std::mutex> lock(mu);
+  Slab* const slabs = g_slabs;
+  int& n = g_nslabs;
+  unsigned long long& tick = g_slab_tick;
+  std::lock_guard<std::mutex> lock(g_slab_mu);
   Slab* e = nullptr;
   for (int i = 0; i < n && !e; ++i)
     if (slabs[i].st == st) e = &slabs[i];

@@ -47,17 +47,22 @@ class _Meters:
         the row count is reduced first and a disagreement raises on every rank."""
         out = {k: AverageMeter() for k in self.names}
         if self.reduce is not None:
-            # (n // 4096, n % 4096) and their squares: all ranks hold the same n  <=>  W * sum(a^2) == (sum a)^2 for both
-            # digits (Cauchy-Schwarz with equality); every value is exact in fp32 for n < 2^24
+            # the count's three base-256 DIGITS and their squares: all ranks hold the same n  <=>  W * sum(d^2) == (sum d)^2 for every
+            # digit (Cauchy-Schwarz with equality).  A square is at most 255^2 and a sum over ranks at most W * 255^2 < 2^24 for
+            # W <= 256, so every partial sum of any reduction order is an exact fp32 integer (with base-4096 digits the cross-rank
+            # sums of squares passed 2^24 and could round: a false mismatch at world >= 3)
             n = len(self.rows)
-            a, b = float(n // 4096), float(n % 4096)
+            if n >= 1 << 24:
+                raise RuntimeError("_Meters.meters(): more than 2^24 rows gathered between two reads")
+            d = [float((n >> (8 * i)) & 255) for i in range(3)]
             dev = self.rows[0].device if self.rows else self.device
-            hdr = torch.tensor([a, a * a, b, b * b], dtype=torch.float32, device=dev)
+            hdr = torch.tensor(d + [x * x for x in d], dtype=torch.float32, device=dev)
             self.reduce(hdr)
-            sa, qa, sb, qb = hdr.cpu().tolist()
-            if qa * self.world != sa * sa or qb * self.world != sb * sb:
+            h = hdr.cpu().tolist()
+            if any(h[3 + i] * self.world != h[i] * h[i] for i in range(3)):
+                mean = sum(h[i] * 256 ** i for i in range(3)) / self.world
                 raise RuntimeError(f"_Meters.meters(): the ranks gathered different numbers of steps since the last read (this rank "
-                                   f"{n}, mean over ranks {(sa * 4096 + sb) / self.world:g}): the loaders' lengths differ, or "
+                                   f"{n}, mean over ranks {mean:g}): the loaders' lengths differ, or "
                                    f"meters() was not called on every rank")
         if self.rows:
             vals = torch.stack(self.rows)

@@ -61,11 +61,11 @@ def _worker(rank, world, port, q):
     for sh in share:
         m.add(sh, 4)                                          # 4 labeled images per rank and step -> global count 8
     out = m.meters()
-    assert calls == [(4,), (2, 4)], calls                     # the row-count header, then ONE collective for both steps
+    assert calls == [(6,), (2, 4)], calls                     # the row-count header (3 digits + squares), then ONE collective for both steps
     assert abs(out["loss"].avg - (0.9 + 1.8) / 2) < 1e-6 and abs(out["acc"].avg - (6.0 / 8 + 3.0 / 8) / 2) < 1e-6
     m.add(share[0], 4)
     out = m.meters()                                          # a later read reduces only the new row
-    assert calls == [(4,), (2, 4), (4,), (1, 4)] and abs(out["loss"].avg - (0.9 + 1.8 + 0.9) / 3) < 1e-6
+    assert calls == [(6,), (2, 4), (6,), (1, 4)] and abs(out["loss"].avg - (0.9 + 1.8 + 0.9) / 3) < 1e-6
     # ranks that gathered different numbers of steps (loaders of different length): the header catches it on EVERY rank before
     # the rows -- buffers of different lengths -- would meet in a collective
     for _ in range(rank + 1):
@@ -75,7 +75,7 @@ def _worker(rank, world, port, q):
         raise AssertionError("a row-count mismatch across ranks went unnoticed")
     except RuntimeError as e:
         assert "different numbers of steps" in str(e)
-    assert calls[-1] == (4,)                                  # only the header was reduced
+    assert calls[-1] == (6,)                                  # only the header was reduced
     # 5. the engine side of the sharded path with world = 2: dist.attach_engine -> Engine.init_comm (unique id made on rank 0,
     #    broadcast over the process group, sslcr_comm_init with this rank / world on every rank) -> steps._meters(engine) ->
     #    Engine.all_reduce_sum -> sslcr_comm_all_reduce_f32.  No GPU here, so the four C-ABI entry points are a stub with the
@@ -124,7 +124,7 @@ def _worker(rank, world, port, q):
     mm.add(rows[0].clone(), 4)
     out = mm.meters()
     assert abs(out["loss"].avg - 0.9) < 1e-6 and abs(out["acc"].avg - 3.0 / 8) < 1e-6
-    assert [e for e in log if e[0] == "all_reduce"] == [("all_reduce", 4), ("all_reduce", 4)]          # header + one row
+    assert [e for e in log if e[0] == "all_reduce"] == [("all_reduce", 6), ("all_reduce", 4)]          # header + one row
     q.put((rank, "ok"))
     dist.destroy_process_group()
 
