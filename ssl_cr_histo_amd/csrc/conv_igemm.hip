@@ -320,6 +320,7 @@ const char* conv_kernel_name(int dtype, const ConvArgs& a) {
   const int tw = q ? 0 : conv_halo_tw(dtype, a);
   if (tw && conv_halo_tw(DT_BF16, a) == tw) return bf ? "sslcr::conv3x3_halo_kernel<unsigned short, ...>" : "sslcr::conv3x3_halo_kernel<float, ...>";
   if (!q && !tw && conv_s2_ok(dtype, a)) return conv_s2_name(a, false);
+  if (!q && !tw && conv_s2d_ok(dtype, a)) return conv_s2d_name();
   const int dbp = (q || tw) ? 0 : conv_dma_bp(dtype, a);
   if (dbp && conv_dma_bp(DT_BF16, a) == dbp) return conv_dma_name(dtype, dbp);
   const int bp = conv_tile_bp(a);
@@ -367,6 +368,7 @@ hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
   const int tw = q ? 0 : conv_halo_tw(dtype, a);
   if (tw && conv_halo_tw(DT_BF16, a) == tw) return launch_conv_halo(dtype, a, tw, st);   // (same tiling in both dtypes)
   if (!q && !tw && conv_s2_ok(dtype, a)) return launch_conv_s2(a, nullptr, st);       // 3x3 / 2 on 16x16 output tiles (rows as conv_dma's)
+  if (!q && !tw && conv_s2d_ok(dtype, a)) return launch_conv_s2d(a, st);             // ... and its dgrad, the four parity classes in one pass
   const int dbp = (q || tw) ? 0 : conv_dma_bp(dtype, a);
   if (dbp && conv_dma_bp(DT_BF16, a) == dbp) return launch_conv_dma(dtype, a, dbp, st);
   if (a.par4) return hipErrorInvalidValue;          // the one-launch parity form exists in the DMA-gather kernel only

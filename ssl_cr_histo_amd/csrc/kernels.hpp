@@ -59,6 +59,10 @@ bool conv_s2_pair_ok(int dtype, const ConvArgs& a, const ConvArgs& d);
 int conv_s2_rows(const ConvArgs& a);
 hipError_t launch_conv_s2(const ConvArgs& a, const ConvArgs* d, hipStream_t st);
 const char* conv_s2_name(const ConvArgs& a, bool pair);
+// conv_s2d.hip: the stride-2 3x3 dgrad, all four output-parity classes in one pass over dY (the par4 descriptor; bf16, 16x16-tileable dY)
+bool conv_s2d_ok(int dtype, const ConvArgs& a);
+hipError_t launch_conv_s2d(const ConvArgs& a, hipStream_t st);
+const char* conv_s2d_name();
 // conv_fp8.hip
 int conv_fp8_mode(const ConvArgs& a);
 int conv_fp8_rows(const ConvArgs& a);

@@ -243,6 +243,23 @@ def test_conv_dgrad(case, dtype):
             close(dx2, want + res, TOL[dtype], "dgrad via flipped pack")
 
 
+@pytest.mark.parametrize("shape", [(6, 64, 64, 64, 128), (9, 32, 32, 128, 256), (70, 64, 64, 64, 128), (3, 32, 64, 256, 384), (130, 32, 32, 128, 256)])
+def test_conv_s2_dgrad(shape):
+    """input gradient of the 3x3 / 2 conv, the four output-parity classes in one pass over dY (conv_s2d_kernel, bf16; the par4
+    descriptor without a residual -- what the engine launches for layer{2,3}.0.conv1): edge tiles (zero halo beyond the bottom /
+    right), 2-6 channel slabs, 1-4 channel blocks, more items than workgroups"""
+    K = _k()
+    N, H, W, C, Ko = shape
+    OH, OW = H // 2, W // 2
+    dy = q(rnd(51, (N, OH, OW, Ko)), 1)
+    w = q(rnd(52, (Ko, 3, 3, C), 0.05), 1)
+    wd = w.permute(3, 1, 2, 0).contiguous()               # [C][R][S][K]
+    dx = torch.full((N, H, W, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    K.conv2d(to_dev(dy, 1), to_dev(wd, 1), 2, 1, transposed=True, out=dx, out_hw=(H, W), pixel_hw=(OH, OW), pix_mul=2, par4=True)
+    assert "conv_s2d_kernel" in K.last_conv_kernel, K.last_conv_kernel
+    close(dx, R.conv_dgrad(dy, w, 2, 1, (H, W)), TOL[1], "stride-2 dgrad")
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 3, 1, 1), (3, 9, 11, 64, 128, 3, 2, 1), (2, 8, 8, 128, 256, 1, 2, 0),
                                   (5, 12, 12, 128, 64, 3, 1, 1), (4, 8, 8, 128, 128, 3, 1, 1), (3, 24, 32, 64, 128, 3, 1, 1),
