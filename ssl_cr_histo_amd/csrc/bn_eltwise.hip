@@ -674,6 +674,95 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a0) {
   }
 }
 
+// ---- a downsampling block's TWO BatchNorms that receive the same gradient (bn2 of the residual branch and the projection
+// shortcut's BatchNorm, torchvision BasicBlock: out = bn2(conv2(..)) + downsample(x) -> both get g = dOut * (y > 0)) in one reduce and
+// one apply pass: g is formed once (a's dy / mask), written once (a.gout) and read once by the apply pass, where the two separate
+// BatchNorm-backward passes read it twice each.  b is the second BatchNorm's descriptor (x, mean, scale, invstd, sums, dx, dgamma ...;
+// its dy is a.gout by construction and is not read).  Same grid, same per-thread element order as the single kernels: both
+// BatchNorms' sums come out with the bits of the separate launches.
+template <typename T, int NB>
+__global__ __launch_bounds__(NB) void bn_bwd_reduce_pair_kernel(const BnBwdArgs a, const BnBwdArgs b, double* __restrict__ rows) {
+  constexpr int EPC = Elem<T>::EPC;
+  extern __shared__ __attribute__((aligned(16))) char bn_red_smem[];
+  float (*sm)[3 * EPC + 1] = reinterpret_cast<float (*)[3 * EPC + 1]>(bn_red_smem);
+  const int cols = a.C / EPC;
+  const int rpp = NB / cols;
+  const int col = threadIdx.x % cols, rl = threadIdx.x / cols;
+  const int cb = col * EPC;
+  float s0[EPC], s1[EPC], s1b[EPC], mean[EPC], meanb[EPC], rsc[EPC], rsh[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    s0[e] = 0.f; s1[e] = 0.f; s1b[e] = 0.f;
+    mean[e] = a.mean[cb + e]; meanb[e] = b.mean[cb + e]; rsc[e] = a.scale[cb + e]; rsh[e] = a.shift[cb + e];
+  }
+  if (rl < rpp) {
+    for (size_t p = (size_t)blockIdx.x * rpp + rl; p < a.pixels; p += (size_t)gridDim.x * rpp) {
+      float g[EPC], xf[EPC], xb[EPC];
+      const size_t i = p * cols + col;
+      bn_bwd_g<T>(a, i, rsc, rsh, g, xf);
+      Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(b.x) + i * 16), xb);
+      st16(reinterpret_cast<char*>(a.gout) + i * 16, Elem<T>::pack(g));
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        s0[e] += g[e];
+        s1[e] = fmaf(g[e], xf[e] - mean[e], s1[e]);
+        s1b[e] = fmaf(g[e], xb[e] - meanb[e], s1b[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) { sm[threadIdx.x][e] = s0[e]; sm[threadIdx.x][EPC + e] = s1[e]; sm[threadIdx.x][2 * EPC + e] = s1b[e]; }
+  __syncthreads();
+  // rows: [BatchNorm (a, b)][workgroup][2][C]; the second BatchNorm's sum of g is the first one's
+  const size_t bstride = (size_t)gridDim.x * 2 * a.C;
+  for (int t = threadIdx.x; t < cols * 3 * EPC; t += NB) {
+    const int cc = t / (3 * EPC), q = t - cc * 3 * EPC;
+    double acc = 0.0;
+    for (int r = 0; r < rpp; ++r) acc += (double)sm[r * cols + cc][q];
+    const int which = q / EPC, e = q - which * EPC;
+    double* ra = rows + ((size_t)blockIdx.x * 2) * a.C + cc * EPC + e;
+    if (which == 0) { ra[0] = acc; ra[bstride] = acc; }
+    else if (which == 1) ra[a.C] = acc;
+    else ra[bstride + a.C] = acc;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(const BnBwdArgs a, const BnBwdArgs b) {
+  constexpr int EPC = Elem<T>::EPC;
+  const int cols = a.C / EPC;
+  const size_t total = a.pixels * cols;
+  const int cb = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % cols) * EPC;
+  float cA[EPC], cB[EPC], cC[EPC], dA[EPC], dB[EPC], dC[EPC];
+  {
+    const float invM = (float)(1.0 / a.count), invMb = (float)(1.0 / b.count);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = cb + e;
+      float is = a.invstd[c], sc = a.scale[c];
+      float m0 = (float)a.sums[c] * invM, m1 = (float)a.sums[a.C + c] * invM;
+      cA[e] = sc; cB[e] = -sc * is * is * m1; cC[e] = -sc * m0 - cB[e] * a.mean[c];
+      is = b.invstd[c]; sc = b.scale[c];
+      m0 = (float)b.sums[c] * invMb; m1 = (float)b.sums[b.C + c] * invMb;
+      dA[e] = sc; dB[e] = -sc * is * is * m1; dC[e] = -sc * m0 - dB[e] * b.mean[c];
+    }
+  }
+  bn_bwd_param_grads(a);
+  bn_bwd_param_grads(b);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    float g[EPC], xa[EPC], xb[EPC], d[EPC];
+    Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.dy) + i * 16), g);
+    Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.x) + i * 16), xa);
+    Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(b.x) + i * 16), xb);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) d[e] = fmaf(cA[e], g[e], fmaf(cB[e], xa[e], cC[e]));
+    st16_nt(reinterpret_cast<char*>(a.dx) + i * 16, Elem<T>::pack(d));
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) d[e] = fmaf(dA[e], g[e], fmaf(dB[e], xb[e], dC[e]));
+    st16_nt(reinterpret_cast<char*>(b.dx) + i * 16, Elem<T>::pack(d));
+  }
+}
+
 // ---- stem form: the gradient arrives through maxpool3x3/2 (pool_dy + argmax codes), see sslcr_bn_bwd_desc.
 // Reduce pass on the POOLED tensors only (4x fewer elements, no 1.3 GB read of x): every pooled gradient lands on exactly one
 // input pixel -- the argmax -- and relu(bn(x)) of that pixel IS the pooled output y, so for y > 0
@@ -897,6 +986,60 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<float, 256>), dim3((int)blocks, nseg), dim3(256), lds, st, a, rows);
   }
   return fold();
+}
+
+// the two-BatchNorm forms (bn_bwd_reduce_pair_kernel): a = the residual branch's bn2 (g_in_reduce: its reduce pass writes g to gout),
+// b = the projection shortcut's BatchNorm on the same g.  b.sums must be a.sums + 2 C (one fold launch, one all-reduce for both).
+bool bn_bwd_pair_ok(const BnBwdArgs& a, const BnBwdArgs& b) {
+  static const bool on = [] { const char* e = getenv("SSLCR_BN_PAIR"); return !e || atoi(e) != 0; }();     // 0: two passes each (A/B runs)
+  return on && a.g_in_reduce && a.gout && b.dy == a.gout && !b.yact && !b.yact_bits && !b.relu_from_x && !b.gout && !a.pool_dy && !b.pool_dy &&
+         a.nseg <= 1 && b.nseg <= 1 && a.C == b.C && a.pixels == b.pixels && b.sums == a.sums + 2 * a.C && a.dx && b.dx && b.x && a.x;
+}
+hipError_t launch_bn_bwd_reduce_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, hipStream_t st) {
+  const int epc = dtype == DT_BF16 ? 8 : 4;
+  const int cols = a.C / epc;
+  if (cols > 256 || (256 % cols) != 0 || !bn_bwd_pair_ok(a, b)) return hipErrorInvalidValue;
+  // the grid of launch_bn_bwd_reduce for this tensor (same rows, same per-thread order: the same sums)
+  const int rpp = 256 / cols;
+  size_t blocks = (a.pixels + rpp - 1) / rpp;
+  blocks = (blocks + 7) / 8;
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  const bool big = blocks >= 512;
+  size_t b4 = 0;
+  if (big) {
+    b4 = ((a.pixels + 1024 / cols - 1) / (1024 / cols) + 7) / 8;
+    if (b4 > 256) b4 = 256;
+  }
+  const int nrows = (int)(big ? b4 : blocks);
+  double* rows = reinterpret_cast<double*>(stream_scratch(st, (size_t)2 * nrows * 2 * a.C * sizeof(double)));
+  if (!rows) return hipErrorOutOfMemory;
+  static std::atomic<bool> attr_done{false};
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_reduce_pair_kernel<bf16_t, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(bn_bwd_reduce_pair_kernel<float, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_done = true;
+  }
+  const int NB = big ? 1024 : 256;
+  const size_t lds = (size_t)NB * (3 * epc + 1) * sizeof(float);
+  if (big) {
+    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<bf16_t, 1024>), dim3(nrows), dim3(1024), lds, st, a, b, rows);
+    else hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<float, 1024>), dim3(nrows), dim3(1024), lds, st, a, b, rows);
+  } else {
+    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<bf16_t, 256>), dim3(nrows), dim3(256), lds, st, a, b, rows);
+    else hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<float, 256>), dim3(nrows), dim3(256), lds, st, a, b, rows);
+  }
+  // one fold for both BatchNorms: "segment" y = the BatchNorm, sums 2 C doubles apart
+  hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(2 * a.C, 64), 2), dim3(64, 16), 0, st, rows, nrows, 2 * a.C, a.sums, 2 * a.C);
+  return hipGetLastError();
+}
+hipError_t launch_bn_bwd_apply_pair(int dtype, const BnBwdArgs& a0, const BnBwdArgs& b, hipStream_t st) {
+  if (!bn_bwd_pair_ok(a0, b)) return hipErrorInvalidValue;
+  BnBwdArgs a = a0;
+  a.dy = a.gout;                                  // the masked gradient the reduce pass left
+  if (dtype == DT_BF16) hipLaunchKernelGGL(bn_bwd_apply_pair_kernel<bf16_t>, dim3(ew_grid(a.pixels * (a.C / 8))), dim3(256), 0, st, a, b);
+  else hipLaunchKernelGGL(bn_bwd_apply_pair_kernel<float>, dim3(ew_grid(a.pixels * (a.C / 4))), dim3(256), 0, st, a, b);
+  return hipGetLastError();
 }
 
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a0, hipStream_t st) {

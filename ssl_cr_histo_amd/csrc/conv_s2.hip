@@ -35,7 +35,11 @@
 namespace sslcr {
 
 #define S2_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#ifdef S2_ABL_NOBAR
+#define S2_BARRIER() asm volatile("" ::: "memory")      /* timing only */
+#else
 #define S2_BARRIER() asm volatile("s_barrier" ::: "memory")
+#endif
 
 #ifndef S2_ABL_MFMA_T
 #define S2_ABL_MFMA_T TK      /* phase bench: 0 compiles the MFMAs out */
@@ -251,12 +255,16 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
       for (int dc = 0; dc < 2; ++dc) Bc[dc][kk] += dlt;
   };
   // fragments of one k-step into register set `buf`
+#ifdef S2_ABL_NOFRAG
+#define S2_FRAGS(buf, kk, DR, DC, P17) do { } while (0)
+#else
 #define S2_FRAGS(buf, kk, DR, DC, P17)                                                                      \
   do {                                                                                                      \
     A[buf][0] = ld16(s_w + Ac[kk]);                                                                         \
     _Pragma("unroll") for (int p = 0; p < TP; ++p) B[buf][p] = ld16(s_halo + Bc[DC][kk] + (p + (DR)) * ((P17) ? 17 * 128 : 16 * 128)); \
     _Pragma("unroll") for (int t = 1; t < TK; ++t) A[buf][t] = ld16(s_w + Ac[kk] + t * 2048);             \
   } while (0)
+#endif
 #define S2_MFMA(buf, SET)                                                                                   \
   do {                                                                                                      \
     _Pragma("unroll") for (int t = 0; t < (S2_ABL_MFMA_T); ++t)                                                          \

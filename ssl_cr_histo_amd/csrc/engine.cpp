@@ -1001,7 +1001,7 @@ double* take_sums_n(sslcr_ctx* c, int nseg) {
 int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy, const void* x, const void* yact, int relu_from_x,
                  void* dx, void* gout, size_t pixels, double count, hipStream_t st, double* sums, BnBwdArgs* out, const PoolSrc* pool = nullptr,
                  int g_in_reduce = 0, const float* sum_rows = nullptr, int n_sum_rows = 0, bool sums_zeroed = false, int nseg = 1,
-                 int seg_stride = 0) {
+                 int seg_stride = 0, bool defer = false) {
   // nseg > 1 (sslcr_bn_bwd_desc.nseg): the tensors hold nseg passes one after the other, `pixels` is their total, sv is pass 0's
   // (the others seg_stride floats apart), `sums` the first of nseg consecutive ring slots, sum_rows / n_sum_rows cover all passes
   sslcr_ctx* c = n->ctx;
@@ -1029,7 +1029,7 @@ int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy,
     r.partials = sum_rows; r.rows = n_sum_rows; r.C = bn.C; r.stage = c->bn_stage; r.sums_out = sums;
     if (nseg > 1) { r.nseg = nseg; r.seg_stride = sslcr_ctx::kBnSlot; }
     TRY(launch_bn_finalize(r, st));
-  } else {
+  } else if (!defer) {                              // (defer: the caller launches the reduce pass itself -- the two-BatchNorm form)
     (void)sums_zeroed;                              // (the reduce pass overwrites its sums)
     TRY(launch_bn_bwd_reduce(c->dtype, a, st));
   }
@@ -1262,13 +1262,39 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
         double* ring = take_sums(c);
         double* sums_2 = ring ? ring : c->bn_sums;
         double* sums_d = sums_2 + 2 * B.b2.C;
+        // both BatchNorms receive the same g = dOut * (y > 0): one reduce pass forms it, writes it once and leaves both pairs of
+        // sums, one apply pass reads it once for both (bn_bwd_reduce_pair_kernel); where that form does not apply, two passes each
         TRYI(bn_bwd_begin(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, sums_2, &a2, nullptr, 1,
-                          nullptr, 0, ring != nullptr));
+                          nullptr, 0, ring != nullptr, 1, 0, true));
         TRYI(bn_bwd_begin(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st, sums_d, &ad, nullptr, 0,
-                          nullptr, 0, ring != nullptr));
+                          nullptr, 0, ring != nullptr, 1, 0, true));
+        const bool pair = bn_bwd_pair_ok(a2, ad);
+        if (pair) {
+          TRY(launch_bn_bwd_reduce_pair(dt, a2, ad, st));
+        } else {
+          TRY(launch_bn_bwd_reduce(dt, a2, st));
+          TRY(launch_bn_bwd_reduce(dt, ad, st));
+        }
         TRYI(bn_bwd_sync(c, sums_2, 4 * (size_t)B.b2.C, st));
-        TRYI(bn_bwd_end(c, a2, st));
-        TRYI(bn_bwd_end(c, ad, st));
+        if (pair) {
+          if (c->prof.on) {
+            ProfRec r;
+            r.e0 = c->prof.get(); r.e1 = c->prof.get();
+            r.name = dt == DT_BF16 ? "sslcr::bn_bwd_apply_pair_kernel<unsigned short>" : "sslcr::bn_bwd_apply_pair_kernel<float>";
+            r.flops = 0.0;
+            r.bytes = 5.0 * (double)opix * B.b2.C * c->esz();         // reads g, x of both BatchNorms; writes both dx
+            (void)hipEventRecord(r.e0, st);
+            hipError_t e = launch_bn_bwd_apply_pair(dt, a2, ad, st);
+            (void)hipEventRecord(r.e1, st);
+            c->prof.rec[2].push_back(r);
+            TRY(e);
+          } else {
+            TRY(launch_bn_bwd_apply_pair(dt, a2, ad, st));
+          }
+        } else {
+          TRYI(bn_bwd_end(c, a2, st));
+          TRYI(bn_bwd_end(c, ad, st));
+        }
       } else {
         TRYI(bn_backward(n, B.b2, ps.bn[B.b2.bidx], dOut, ps.blk[i].raw2, ps.blk[i].y, 0, dRaw2, G, opix, (double)opix, st, nullptr, 1));
       }

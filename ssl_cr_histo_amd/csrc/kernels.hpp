@@ -99,6 +99,10 @@ hipError_t launch_avgpool_fwd(int dtype, const void* x, float* y, int N, int HW,
 hipError_t launch_avgpool_bwd(int dtype, const float* dy, void* dx, int N, int HW, int C, hipStream_t st);
 hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st);
+// a downsampling block's two BatchNorms on one gradient (bn2 + the projection's): one reduce and one apply pass for both
+bool bn_bwd_pair_ok(const BnBwdArgs& a, const BnBwdArgs& b);
+hipError_t launch_bn_bwd_reduce_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, hipStream_t st);
+hipError_t launch_bn_bwd_apply_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, hipStream_t st);
 hipError_t launch_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, hipStream_t st);
 hipError_t launch_bn_param_grads_scaled(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, float scale, hipStream_t st);
 // heads.hip
