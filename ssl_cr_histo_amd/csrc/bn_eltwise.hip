@@ -680,8 +680,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a0) {
 // BatchNorm-backward passes read it twice each.  b is the second BatchNorm's descriptor (x, mean, scale, invstd, sums, dx, dgamma ...;
 // its dy is a.gout by construction and is not read).  Same grid, same per-thread element order as the single kernels: both
 // BatchNorms' sums come out with the bits of the separate launches.
+// keep_g = 0: g is not written at all -- the apply pass forms it again from (dy, mask bits): one tensor write and one read less for
+// 1/16 of a read (the engine's choice where nothing else reads g: a downsampling block has no identity path)
 template <typename T, int NB>
-__global__ __launch_bounds__(NB) void bn_bwd_reduce_pair_kernel(const BnBwdArgs a, const BnBwdArgs b, double* __restrict__ rows) {
+__global__ __launch_bounds__(NB) void bn_bwd_reduce_pair_kernel(const BnBwdArgs a, const BnBwdArgs b, double* __restrict__ rows, const int keep_g) {
   constexpr int EPC = Elem<T>::EPC;
   extern __shared__ __attribute__((aligned(16))) char bn_red_smem[];
   float (*sm)[3 * EPC + 1] = reinterpret_cast<float (*)[3 * EPC + 1]>(bn_red_smem);
@@ -701,7 +703,7 @@ __global__ __launch_bounds__(NB) void bn_bwd_reduce_pair_kernel(const BnBwdArgs 
       const size_t i = p * cols + col;
       bn_bwd_g<T>(a, i, rsc, rsh, g, xf);
       Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(b.x) + i * 16), xb);
-      st16(reinterpret_cast<char*>(a.gout) + i * 16, Elem<T>::pack(g));
+      if (keep_g) st16(reinterpret_cast<char*>(a.gout) + i * 16, Elem<T>::pack(g));
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
         s0[e] += g[e];
@@ -728,12 +730,12 @@ __global__ __launch_bounds__(NB) void bn_bwd_reduce_pair_kernel(const BnBwdArgs 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(const BnBwdArgs a, const BnBwdArgs b) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(const BnBwdArgs a, const BnBwdArgs b, const int from_g) {
   constexpr int EPC = Elem<T>::EPC;
   const int cols = a.C / EPC;
   const size_t total = a.pixels * cols;
   const int cb = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) % cols) * EPC;
-  float cA[EPC], cB[EPC], cC[EPC], dA[EPC], dB[EPC], dC[EPC];
+  float cA[EPC], cB[EPC], cC[EPC], dA[EPC], dB[EPC], dC[EPC], rsc[EPC], rsh[EPC];
   {
     const float invM = (float)(1.0 / a.count), invMb = (float)(1.0 / b.count);
 #pragma unroll
@@ -742,6 +744,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(const BnBwdArgs 
       float is = a.invstd[c], sc = a.scale[c];
       float m0 = (float)a.sums[c] * invM, m1 = (float)a.sums[a.C + c] * invM;
       cA[e] = sc; cB[e] = -sc * is * is * m1; cC[e] = -sc * m0 - cB[e] * a.mean[c];
+      rsc[e] = sc; rsh[e] = a.shift[c];
       is = b.invstd[c]; sc = b.scale[c];
       m0 = (float)b.sums[c] * invMb; m1 = (float)b.sums[b.C + c] * invMb;
       dA[e] = sc; dB[e] = -sc * is * is * m1; dC[e] = -sc * m0 - dB[e] * b.mean[c];
@@ -751,8 +754,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pair_kernel(const BnBwdArgs 
   bn_bwd_param_grads(b);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     float g[EPC], xa[EPC], xb[EPC], d[EPC];
-    Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.dy) + i * 16), g);
-    Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.x) + i * 16), xa);
+    if (from_g) {
+      Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.gout) + i * 16), g);
+      Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(a.x) + i * 16), xa);
+    } else {
+      bn_bwd_g<T>(a, i, rsc, rsh, g, xa);          // (dy, mask) again: the reduce pass kept no g
+    }
     Elem<T>::unpack(ld16_nt(reinterpret_cast<const char*>(b.x) + i * 16), xb);
 #pragma unroll
     for (int e = 0; e < EPC; ++e) d[e] = fmaf(cA[e], g[e], fmaf(cB[e], xa[e], cC[e]));
@@ -995,7 +1002,7 @@ bool bn_bwd_pair_ok(const BnBwdArgs& a, const BnBwdArgs& b) {
   return on && a.g_in_reduce && a.gout && b.dy == a.gout && !b.yact && !b.yact_bits && !b.relu_from_x && !b.gout && !a.pool_dy && !b.pool_dy &&
          a.nseg <= 1 && b.nseg <= 1 && a.C == b.C && a.pixels == b.pixels && b.sums == a.sums + 2 * a.C && a.dx && b.dx && b.x && a.x;
 }
-hipError_t launch_bn_bwd_reduce_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, hipStream_t st) {
+hipError_t launch_bn_bwd_reduce_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, int keep_g, hipStream_t st) {
   const int epc = dtype == DT_BF16 ? 8 : 4;
   const int cols = a.C / epc;
   if (cols > 256 || (256 % cols) != 0 || !bn_bwd_pair_ok(a, b)) return hipErrorInvalidValue;
@@ -1023,22 +1030,20 @@ hipError_t launch_bn_bwd_reduce_pair(int dtype, const BnBwdArgs& a, const BnBwdA
   const int NB = big ? 1024 : 256;
   const size_t lds = (size_t)NB * (3 * epc + 1) * sizeof(float);
   if (big) {
-    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<bf16_t, 1024>), dim3(nrows), dim3(1024), lds, st, a, b, rows);
-    else hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<float, 1024>), dim3(nrows), dim3(1024), lds, st, a, b, rows);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<bf16_t, 1024>), dim3(nrows), dim3(1024), lds, st, a, b, rows, keep_g);
+    else hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<float, 1024>), dim3(nrows), dim3(1024), lds, st, a, b, rows, keep_g);
   } else {
-    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<bf16_t, 256>), dim3(nrows), dim3(256), lds, st, a, b, rows);
-    else hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<float, 256>), dim3(nrows), dim3(256), lds, st, a, b, rows);
+    if (dtype == DT_BF16) hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<bf16_t, 256>), dim3(nrows), dim3(256), lds, st, a, b, rows, keep_g);
+    else hipLaunchKernelGGL((bn_bwd_reduce_pair_kernel<float, 256>), dim3(nrows), dim3(256), lds, st, a, b, rows, keep_g);
   }
   // one fold for both BatchNorms: "segment" y = the BatchNorm, sums 2 C doubles apart
   hipLaunchKernelGGL(bn_bwd_sums_kernel, dim3(cdiv(2 * a.C, 64), 2), dim3(64, 16), 0, st, rows, nrows, 2 * a.C, a.sums, 2 * a.C);
   return hipGetLastError();
 }
-hipError_t launch_bn_bwd_apply_pair(int dtype, const BnBwdArgs& a0, const BnBwdArgs& b, hipStream_t st) {
-  if (!bn_bwd_pair_ok(a0, b)) return hipErrorInvalidValue;
-  BnBwdArgs a = a0;
-  a.dy = a.gout;                                  // the masked gradient the reduce pass left
-  if (dtype == DT_BF16) hipLaunchKernelGGL(bn_bwd_apply_pair_kernel<bf16_t>, dim3(ew_grid(a.pixels * (a.C / 8))), dim3(256), 0, st, a, b);
-  else hipLaunchKernelGGL(bn_bwd_apply_pair_kernel<float>, dim3(ew_grid(a.pixels * (a.C / 4))), dim3(256), 0, st, a, b);
+hipError_t launch_bn_bwd_apply_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, int from_g, hipStream_t st) {
+  if (!bn_bwd_pair_ok(a, b)) return hipErrorInvalidValue;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(bn_bwd_apply_pair_kernel<bf16_t>, dim3(ew_grid(a.pixels * (a.C / 8))), dim3(256), 0, st, a, b, from_g);
+  else hipLaunchKernelGGL(bn_bwd_apply_pair_kernel<float>, dim3(ew_grid(a.pixels * (a.C / 4))), dim3(256), 0, st, a, b, from_g);
   return hipGetLastError();
 }
 

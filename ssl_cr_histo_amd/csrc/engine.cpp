@@ -1269,8 +1269,13 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
         TRYI(bn_bwd_begin(n, B.bd, ps.bn[B.bd.bidx], G, ps.blk[i].rawd, nullptr, 0, dRawD, nullptr, opix, (double)opix, st, sums_d, &ad, nullptr, 0,
                           nullptr, 0, ring != nullptr, 1, 0, true));
         const bool pair = bn_bwd_pair_ok(a2, ad);
+        // (g is read by nobody else in a downsampling block, so with the mask as bits it need not be written at all -- measured
+        //  SLOWER, 15.81 -> 15.90 ms same box: forming g from (dOut, bits) a second time costs the apply pass more than reading it.
+        //  SSLCR_BN_PAIR_G=0 selects that form; the debug tap always keeps g)
+        static const bool g_free = [] { const char* e = getenv("SSLCR_BN_PAIR_G"); return e && atoi(e) == 0; }();
+        const int keep_g = (n->tap || !a2.yact_bits || !g_free) ? 1 : 0;
         if (pair) {
-          TRY(launch_bn_bwd_reduce_pair(dt, a2, ad, st));
+          TRY(launch_bn_bwd_reduce_pair(dt, a2, ad, keep_g, st));
         } else {
           TRY(launch_bn_bwd_reduce(dt, a2, st));
           TRY(launch_bn_bwd_reduce(dt, ad, st));
@@ -1282,14 +1287,14 @@ int backbone_backward(sslcr_net* n, int npass, hipStream_t st) {
             r.e0 = c->prof.get(); r.e1 = c->prof.get();
             r.name = dt == DT_BF16 ? "sslcr::bn_bwd_apply_pair_kernel<unsigned short>" : "sslcr::bn_bwd_apply_pair_kernel<float>";
             r.flops = 0.0;
-            r.bytes = 5.0 * (double)opix * B.b2.C * c->esz();         // reads g, x of both BatchNorms; writes both dx
+            r.bytes = (keep_g ? 5.0 : 5.0625) * (double)opix * B.b2.C * c->esz();   // reads g (or dy + mask bits), x of both BatchNorms; writes both dx
             (void)hipEventRecord(r.e0, st);
-            hipError_t e = launch_bn_bwd_apply_pair(dt, a2, ad, st);
+            hipError_t e = launch_bn_bwd_apply_pair(dt, a2, ad, keep_g, st);
             (void)hipEventRecord(r.e1, st);
             c->prof.rec[2].push_back(r);
             TRY(e);
           } else {
-            TRY(launch_bn_bwd_apply_pair(dt, a2, ad, st));
+            TRY(launch_bn_bwd_apply_pair(dt, a2, ad, keep_g, st));
           }
         } else {
           TRYI(bn_bwd_end(c, a2, st));

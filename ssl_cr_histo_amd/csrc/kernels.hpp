@@ -101,8 +101,9 @@ hipError_t launch_bn_bwd_reduce(int dtype, const BnBwdArgs& a, hipStream_t st);
 hipError_t launch_bn_bwd_apply(int dtype, const BnBwdArgs& a, hipStream_t st);
 // a downsampling block's two BatchNorms on one gradient (bn2 + the projection's): one reduce and one apply pass for both
 bool bn_bwd_pair_ok(const BnBwdArgs& a, const BnBwdArgs& b);
-hipError_t launch_bn_bwd_reduce_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, hipStream_t st);
-hipError_t launch_bn_bwd_apply_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, hipStream_t st);
+// keep_g / from_g = 0: g is never written; the apply pass forms it again from (dy, mask)
+hipError_t launch_bn_bwd_reduce_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, int keep_g, hipStream_t st);
+hipError_t launch_bn_bwd_apply_pair(int dtype, const BnBwdArgs& a, const BnBwdArgs& b, int from_g, hipStream_t st);
 hipError_t launch_bn_param_grads(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, hipStream_t st);
 hipError_t launch_bn_param_grads_scaled(const double* sums, const float* invstd, float* dgamma, float* dbeta, int C, float scale, hipStream_t st);
 // heads.hip
