@@ -282,6 +282,7 @@ const char* wgrad_kernel_name(int dtype, const WgradArgs& a) {
   const bool wide = bf && a.K % 128 == 0;          // the 128-kout block, 8-wave form (wgrad_halo.hip)
   if (tw == 16) return bf ? (wide ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 16, 2>" : "sslcr::wgrad3x3_halo_kernel<unsigned short, 16, 1>") : "sslcr::wgrad3x3_halo_kernel<float, 16, 1>";
   if (tw == 8) return bf ? (wide ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 8, 2>" : "sslcr::wgrad3x3_halo_kernel<unsigned short, 8, 1>") : "sslcr::wgrad3x3_halo_kernel<float, 8, 1>";
+  if (wgrad_s2_ok(dtype, a)) return a.OW % 16 == 0 ? "sslcr::wgrad_s2_kernel<16>" : "sslcr::wgrad_s2_kernel<8>";
   const bool kw = wgrad_wide(dtype, a);
   if (a.R == 3) return bf ? (kw ? "sslcr::wgrad_kernel<unsigned short, 9, 2>" : "sslcr::wgrad_kernel<unsigned short, 9, 1>") : "sslcr::wgrad_kernel<float, 9, 1>";
   return bf ? (kw ? "sslcr::wgrad_kernel<unsigned short, 1, 2>" : "sslcr::wgrad_kernel<unsigned short, 1, 1>") : "sslcr::wgrad_kernel<float, 1, 1>";
@@ -291,6 +292,7 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t st) {
   const int tw = wgrad_halo_tw(a);
   if (tw) return launch_wgrad_halo(dtype, a, tw, st);
   if (a.seg_images > 0 && a.seg_images < a.N) return hipErrorInvalidValue;      // per-segment prologue: halo kernel only
+  if (wgrad_s2_ok(dtype, a)) return launch_wgrad_s2(a, st);                     // 3x3 / 2 on 4x16-tileable output maps: parity-plane halo form
   const bool three = a.R == 3;
   if (wgrad_wide(dtype, a)) return three ? launch_w<bf16_t, 9, 2>(a, st) : launch_w<bf16_t, 1, 2>(a, st);
   if (dtype == DT_BF16) return three ? launch_w<bf16_t, 9, 1>(a, st) : launch_w<bf16_t, 1, 1>(a, st);

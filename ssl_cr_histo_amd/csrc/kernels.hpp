@@ -82,6 +82,9 @@ hipError_t launch_wgrad_fold(const void* slabs, float* dw, int C, int gx, int gy
 hipError_t launch_stem_wgrad_fold(const void* slabs, float* dw, int nwg, hipStream_t st);
 hipError_t launch_wgrad_halo(int dtype, const WgradArgs& a, int tw, hipStream_t st);
 hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, hipStream_t st);
+// wgrad_s2.hip: 3x3 / 2 weight gradient with the input region staged once per tile as parity planes (bf16, no producer transform)
+bool wgrad_s2_ok(int dtype, const WgradArgs& a);
+hipError_t launch_wgrad_s2(const WgradArgs& a, hipStream_t st);
 // stem.hip
 hipError_t launch_stem(int dtype, const StemArgs& a, hipStream_t st);
 int stem_partials_rows(const StemArgs& a);

@@ -243,6 +243,24 @@ def test_conv_dgrad(case, dtype):
             close(dx2, want + res, TOL[dtype], "dgrad via flipped pack")
 
 
+@pytest.mark.parametrize("shape", [(6, 64, 64, 64, 128), (9, 32, 32, 128, 256), (70, 64, 64, 64, 128), (3, 8, 32, 192, 384), (130, 32, 32, 128, 256),
+                                   (40, 16, 16, 256, 512), (3, 32, 16, 64, 128)])      # last two: 8-wide maps (whole 8x8 images / two tiles per image)
+def test_conv_s2_wgrad(shape):
+    """weight gradient of the 3x3 / 2 conv in parity-plane halo form (wgrad_s2_kernel, bf16, no producer transform -- what the engine
+    launches for layer{2,3}.0.conv1): image-edge tiles (zero row / column), 1-3 cin blocks, 1-3 kout blocks, several pixel splits
+    through the ordered fold, accumulation into a non-zero dW"""
+    K = _k()
+    N, H, W, C, Ko = shape
+    OH, OW = H // 2, W // 2
+    x = q(rnd(61, (N, H, W, C)), 1)
+    dy = q(rnd(62, (N, OH, OW, Ko)), 1)
+    base = rnd(63, (Ko, 3, 3, C))
+    dw = base.clone().to(DEV)
+    K.conv2d_wgrad(to_dev(x, 1), to_dev(dy, 1), dw, 3, 3, 2, 1)
+    want = R.conv_wgrad(x, dy, (Ko, 3, 3, C), 2, 1)
+    close(dw.cpu() - base, want, 3e-3, "stride-2 wgrad")
+
+
 @pytest.mark.parametrize("shape", [(6, 64, 64, 64, 128), (9, 32, 32, 128, 256), (70, 64, 64, 64, 128), (3, 32, 64, 256, 384), (130, 32, 32, 128, 256)])
 def test_conv_s2_dgrad(shape):
     """input gradient of the 3x3 / 2 conv, the four output-parity classes in one pass over dY (conv_s2d_kernel, bf16; the par4
