@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 F_FWD = 2 * 2368733184            # backbone forward FLOPs per 256x256 image
 F_BWD_FULL = 2 * F_FWD - 0.308e9  # + dgrad + wgrad, no dgrad for conv1
-PMC_FILE = os.path.join("profiles", "r04d_final_pmc_step.json")     # fallback only (tools/pmc_step.sh on the builder's lease): the line's
+PMC_FILE = os.path.join("profiles", "r05_final_pmc_step.json")     # fallback only (tools/pmc_step.sh on the builder's lease): the line's
                                                               # counters are measured IN this run by pmc_in_run() when rocprofv3 is there
 
 
