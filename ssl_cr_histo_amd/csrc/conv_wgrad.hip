@@ -17,11 +17,17 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 template <typename T> struct WgFrag;
 template <> struct WgFrag<bf16_t> {
   static constexpr int PS = 32;          // pixels per step = one 16x16x32 MFMA depth
-  // tile: [PS][128B]; (col0 = first of 16 channels) -> fragment of lane (li,g): pixels 8g..8g+7 of channel col0+li
+  // tile: [PS][128B], the 32-byte column group XORed with bits 1..2 of the row (swz_off); (col0 = first of 16 channels) -> fragment of
+  // lane (li, g): eight pixels of channel col0 + li.  Which eight is free as long as dY and X use the same map: rows pl and pl + 8
+  // with pl = 16 (g >> 1) + 4 (g & 1) + (li >> 2), so that the eight rows a 32-lane half presents to the transpose read are eight
+  // CONSECUTIVE rows -- with the swizzle conflict-free (wgrad_halo.hip).  (Until round 5 this kernel read rows 8 g + (li >> 2) and
+  // + 4 of an unswizzled tile: SQ_LDS_BANK_CONFLICT = 65 % of its LDS cycles, profiles/r05_s2_lds_bank_conflicts.txt.)
+  __device__ static __forceinline__ int swz_off(int row, int ch) { return (((ch >> 1) ^ ((row >> 1) & 3)) << 5) | ((ch & 1) << 4); }
   __device__ static __forceinline__ bf16x8_t load(const char* tile, int col0, int li, int g) {
-    const char* p = tile + (8 * g + (li >> 2)) * 128 + (col0 + (li & 3) * 4) * 2;
+    const int pl = 16 * (g >> 1) + 4 * (g & 1) + (li >> 2);
+    const char* p = tile + pl * 128 + (((col0 >> 4) ^ ((pl >> 1) & 3)) << 5) + (li & 3) * 8;
     s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
-    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 4 * 128));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 8 * 128));
     typedef short s16x8_t __attribute__((ext_vector_type(8)));
     s16x8_t v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8_t, v);
@@ -137,7 +143,8 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad_kernel(const WgradArgs a, i
   };
   auto store_lds = [&](int buf) {
     char* b = smem + buf * BUF;
-    st16(b + kh * TILE + row * RB + chunk * 16, yreg);
+    const int coff = BF ? WgFrag<bf16_t>::swz_off(row, chunk) : chunk * 16;      // (fp32 tiles: scalar reads, no swizzle)
+    st16(b + kh * TILE + row * RB + coff, yreg);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int t = KH * i + kh;
@@ -153,7 +160,7 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad_kernel(const WgradArgs a, i
         }
         v = Elem<T>::pack(f);
       }
-      st16(b + (KH + t) * TILE + row * RB + chunk * 16, v);
+      st16(b + (KH + t) * TILE + row * RB + coff, v);
     }
   };
 
