@@ -94,3 +94,33 @@ def sup_grads(kind, p, x, y, emulate):
     loss = F.mse_loss(logits, y.view(-1, 1)) if kind == "mse" else F.cross_entropy(logits, y)
     loss.backward()
     return {k: v.grad.clone() for k, v in p.items()}, logits.detach(), float(loss.detach())
+
+
+def backbone_eval(p, b, x, q=rnd, pre="model."):
+    """eval-mode resnet18 backbone the way the engine's bf16 mode runs the TEACHER: BatchNorm's running statistics folded
+    into the filters (w * gamma / sqrt(var + eps), rounded to bf16 AFTER the fold; the shift stays fp32 as the conv's
+    bias), every conv output stored in bf16 after its bias / residual / ReLU epilogue (q = identity gives fp32)."""
+    def conv(x, cname, bname, stride, pad):
+        s = p[pre + bname + ".weight"] / torch.sqrt(b[pre + bname + ".running_var"] + 1e-5)
+        sh = p[pre + bname + ".bias"] - b[pre + bname + ".running_mean"] * s
+        return F.conv2d(x, q(p[pre + cname + ".weight"] * s.view(-1, 1, 1, 1)), sh, stride, pad)
+    x = q(x)
+    x = F.max_pool2d(q(F.relu(conv(x, "conv1", "bn1", 2, 3))), 3, 2, 1)
+    for name, cin, cout, stride, ds in M.BLOCKS:
+        o = q(F.relu(conv(x, name + ".conv1", name + ".bn1", stride, 1)))
+        i = q(conv(x, name + ".downsample.0", name + ".downsample.1", stride, 0)) if ds else x
+        x = q(F.relu(conv(o, name + ".conv2", name + ".bn2", 1, 1) + i))
+    return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+
+
+def teacher_logits(p, b, u_w, emulate, chunk=64):
+    """the teacher's logits on the weakly augmented unlabeled batch (eval_BreastPathQ_SSL_CR.py:115-121: eval mode,
+    no_grad, TripletNet_Finetune de-triplicated), bf16-emulated or plain."""
+    q = rnd if emulate else (lambda t: t)
+    with torch.no_grad():
+        out = []
+        for i in range(0, u_w.shape[0], chunk):
+            e = backbone_eval(p, b, u_w[i:i + chunk], q)
+            f = M.fc_head(p, torch.cat((e, e), 1))
+            out.append(M.classifier_forward(p, torch.cat((f, f, f), 1)))
+        return torch.cat(out)

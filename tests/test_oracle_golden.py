@@ -1,5 +1,6 @@
 """Pin the CPU oracle (oracle/) against the golden vectors captured from the REFERENCE's own
 train()/validate() (tests/golden/make_golden.py).  CPU only."""
+import os
 import pytest
 import numpy as np
 import torch
@@ -325,3 +326,34 @@ def test_flip_yardstick_names_a_head_unit_fp32_cannot_resolve():
         e = {i: B.backbone_train(p, (i1, i2, i3)[i].float(), lambda t: t) for i in pair}
         z = F.linear(torch.cat((e[pair[0]], e[pair[1]]), 1), p["fc.0.weight"], p["fc.0.bias"])
     assert abs(float(z[int(u[1]), int(u[2])])) < 1e-5 * float(z.pow(2).mean().sqrt())
+
+
+def test_bf16_teacher_emulation_is_the_eval_forward_when_nothing_is_rounded():
+    """oracle/bf16_emul.py:backbone_eval (BatchNorm folded into the filters, the engine's teacher path) with q = identity is the
+    eval-mode backbone of oracle/model.py, so the only difference of the emulated run is the rounding."""
+    from oracle import bf16_emul as B
+    p_net, b_net, p_cls = oracle_state("finetune", 1, True)
+    p = {k: v.double() for k, v in merged(p_net, p_cls).items()}
+    b = {k: v.double() if v.is_floating_point() else v for k, v in b_net.items()}
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(5), dtype=torch.float64)
+    with torch.no_grad():
+        want = OM.backbone_forward(p, dict(b), x, False)
+        got = B.backbone_eval(p, b, x, lambda t: t)
+        lt = B.teacher_logits(p, b, x, False)
+        assert rel_err(got, want) < 1e-12
+        assert rel_err(lt, OM.classifier_forward(p, OM.finetune_forward(p, dict(b), x, False, True))) < 1e-12
+        assert 1e-4 < rel_err(B.backbone_eval({k: v.float() for k, v in p.items()}, {k: v.float() if v.is_floating_point() else v for k, v in b.items()},
+                                              x.float(), B.rnd).double(), want) < 3e-2
+
+
+@pytest.mark.parametrize("name", ["bpq_cr_full", "cam_cr_full"])
+def test_bf16_yardstick_is_pinned_to_the_reference(name):
+    """tests/golden/bf16_yard.npz (make_bf16_yard.py, oracle only): its float64 run returns the losses the REFERENCE's own
+    iteration returned (golden `ret`), so the emulated run next to it measures bf16 storage on that very iteration; the
+    emulation covers the teacher too (its error dominates the BreastPathQ consistency loss: 1.4e-3 on the teacher's logits)."""
+    y = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_yard.npz"))
+    g = load_golden(name)
+    assert np.allclose(y[f"{name}/ret_f64"], g[f"{name}/ret"][:3], rtol=2e-6, atol=0)
+    assert np.allclose(y[f"{name}/ret_bf16emul"], y[f"{name}/ret_f64"], rtol=5e-3, atol=0)
+    assert int(y[f"{name}/argmax_flips"][0]) == 0
+    assert 1e-4 < float(y[f"{name}/teacher_logits_err"][0]) < 5e-3 and 1e-3 < float(y[f"{name}/feats_err"][0]) < 2e-2
