@@ -125,6 +125,8 @@ typedef struct sslcr_wgrad_desc {
                           /* (the TripletNet branches as one batch: dW is linear in the pixels, their statistics are per branch)    */
 } sslcr_wgrad_desc;
 int sslcr_conv2d_wgrad(int dtype, const sslcr_wgrad_desc* d, void* stream);
+/* name of the kernel instance sslcr_conv2d_wgrad would launch for this descriptor (static string, as sslcr_conv2d_kernel_name) */
+const char* sslcr_conv2d_wgrad_kernel_name(int dtype, const sslcr_wgrad_desc* d);
 
 /* diagnostics: lane l of one wave performs ds_read_b64_tr_b16 at byte_addr[l] of a 2 KiB LDS copy of `in`; out[l][0..3] */
 int sslcr_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, void* stream);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "sslcr_conv2d_fp8_partial_rows": (i32, [P(ConvDesc)]),
     "sslcr_pack_conv_fp8": (i32, [P(PackFp8Desc), vp]),
     "sslcr_conv2d_wgrad": (i32, [i32, P(WgradDesc), vp]),
+    "sslcr_conv2d_wgrad_kernel_name": (C.c_char_p, [i32, P(WgradDesc)]),
     "sslcr_probe_tr16": (i32, [vp, vp, vp, vp]),
     "sslcr_stem_conv": (i32, [i32, P(StemDesc), vp]),
     "sslcr_stem_partial_rows": (i32, [P(StemDesc)]),

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsslcr.so")
-SOURCES = ["conv_igemm.hip", "conv_halo.hip", "conv_halo256.hip", "conv_h16.hip", "conv_pp64.hip", "conv_dma.hip", "conv_s2.hip", "conv_s2d.hip", "conv_fp8.hip", "conv_wgrad.hip", "wgrad_halo.hip", "wgrad_s2.hip","stem.hip", "stem_pool.hip", "augment.hip", "bn_eltwise.hip", "heads.hip", "optim.hip",
+SOURCES = ["conv_igemm.hip", "conv_halo.hip", "conv_halo256.hip", "conv_h16.hip", "conv_pp64.hip", "conv_dma.hip", "conv_s2.hip", "conv_s2d.hip", "conv_fp8.hip", "conv_wgrad.hip", "wgrad_halo.hip", "wgrad_dma.hip", "wgrad_s2.hip", "stem.hip", "stem_pool.hip", "augment.hip", "bn_eltwise.hip", "heads.hip", "optim.hip",
            "engine.cpp", "capi.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fvisibility=hidden"]
 # No SLP vectoriser where a wave's VALU work runs BESIDE its SIMD partner's MFMA stream (the ping-pong conv, the role-split stem

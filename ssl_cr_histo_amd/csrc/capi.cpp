@@ -69,6 +69,7 @@ int sslcr_pack_conv_fp8(const sslcr_pack_fp8_desc* d, void* stream) {
   return check(launch_pack_fp8(*d, (hipStream_t)stream), "pack_conv_fp8");
 }
 
+const char* sslcr_conv2d_wgrad_kernel_name(int dtype, const sslcr_wgrad_desc* d) { return d ? wgrad_kernel_name(dtype, *d) : ""; }
 int sslcr_conv2d_wgrad(int dtype, const sslcr_wgrad_desc* d, void* stream) {
   DT_OK(dtype);
   NEED(d && d->x && d->dy && d->dw, "null tensor");

@@ -287,6 +287,11 @@ const char* wgrad_kernel_name(int dtype, const WgradArgs& a) {
   const bool bf = dtype == DT_BF16;
   const int tw = wgrad_halo_tw(a);
   const bool wide = bf && a.K % 128 == 0;          // the 128-kout block, 8-wave form (wgrad_halo.hip)
+  if (tw && wgrad_dma_used(dtype, a)) {
+    const bool xf = a.in_scale != nullptr;
+    if (tw == 16) return xf ? "sslcr::wgrad3x3_dma_kernel<16, true>" : "sslcr::wgrad3x3_dma_kernel<16, false>";
+    return xf ? "sslcr::wgrad3x3_dma_kernel<8, true>" : "sslcr::wgrad3x3_dma_kernel<8, false>";
+  }
   if (tw == 16) return bf ? (wide ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 16, 2>" : "sslcr::wgrad3x3_halo_kernel<unsigned short, 16, 1>") : "sslcr::wgrad3x3_halo_kernel<float, 16, 1>";
   if (tw == 8) return bf ? (wide ? "sslcr::wgrad3x3_halo_kernel<unsigned short, 8, 2>" : "sslcr::wgrad3x3_halo_kernel<unsigned short, 8, 1>") : "sslcr::wgrad3x3_halo_kernel<float, 8, 1>";
   if (wgrad_s2_ok(dtype, a)) return a.OW % 16 == 0 ? "sslcr::wgrad_s2_kernel<16>" : "sslcr::wgrad_s2_kernel<8>";

@@ -81,6 +81,10 @@ void stream_scratch_release();      // frees every stream's scratch (sslcr_destr
 hipError_t launch_wgrad_fold(const void* slabs, float* dw, int C, int gx, int gy, int splits, int taps, int kh_n, hipStream_t st);
 hipError_t launch_stem_wgrad_fold(const void* slabs, float* dw, int nwg, hipStream_t st);
 hipError_t launch_wgrad_halo(int dtype, const WgradArgs& a, int tw, hipStream_t st);
+// wgrad_dma.hip: the halo kernel's 128-kout bf16 instances with the operands staged by LDS DMA (same tiles, slabs and bits)
+bool wgrad_dma_ok(int dtype, const WgradArgs& a, int splits);
+bool wgrad_dma_used(int dtype, const WgradArgs& a);
+hipError_t launch_wgrad_dma(const WgradArgs& a, int tw, int tps, int ntiles, int splits, void* slabs, hipStream_t st);
 hipError_t launch_probe_tr16(const uint16_t* in, const int* byte_addr, uint16_t* out, hipStream_t st);
 // wgrad_s2.hip: 3x3 / 2 weight gradient with the input region staged once per tile as parity planes (bf16, no producer transform)
 bool wgrad_s2_ok(int dtype, const WgradArgs& a);

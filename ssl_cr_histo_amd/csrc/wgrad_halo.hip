@@ -454,27 +454,38 @@ int wgrad_halo_tw(const WgradArgs& a) {
   return 0;
 }
 
+// pixel splits of a launch: exactly one resident round (two workgroups per CU for KH = 1, one 8-wave workgroup for KH = 2), at least
+// 16 tiles per workgroup -- below that the slab of its 64x64x9 block outweighs the parallelism (RSP N=128: +4 % step)
+static int wh_splits(const WgradArgs& a, int TW, int KH, int* tps_out, int* ntiles_out) {
+  const int NI = 128 / (8 * TW);
+  const int ntiles = (a.N / NI) * (a.H / 8) * (a.W / TW);
+  const int kc = (a.K / (64 * KH)) * (a.C / 64);
+  int splits = cdiv((KH == 1 ? 2 : 1) * device_cus(), kc);
+  const int max_splits = cdiv(ntiles, 16);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int tps = cdiv(ntiles, splits);
+  if (tps_out) *tps_out = tps;
+  if (ntiles_out) *ntiles_out = ntiles;
+  return cdiv(ntiles, tps);
+}
+// does the DMA form (wgrad_dma.hip) serve this launch?
+bool wgrad_dma_used(int dtype, const WgradArgs& a) {
+  const int tw = wgrad_halo_tw(a);
+  if (!tw || dtype != DT_BF16 || a.K % 128 != 0) return false;
+  return wgrad_dma_ok(dtype, a, wh_splits(a, tw, 2, nullptr, nullptr));
+}
+
 template <typename T, int TW, int KH>
 static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   constexpr bool BF = Elem<T>::DT == DT_BF16;
   constexpr int NI = 128 / (8 * TW);
-  constexpr int HP = NI * 10 * (TW + 2);
-  const int ntiles = (a.N / NI) * (a.H / 8) * (a.W / TW);
-  const int kc = (a.K / (64 * KH)) * (a.C / 64);
-  // exactly one resident round: two workgroups per CU.  The pixel split decides how many accumulator slabs are written and folded
-  // (workgroups x 64x64x9 floats).
-  const int cus = device_cus();
-  int splits = cdiv((KH == 1 ? 2 : 1) * cus, kc);        // KH == 2: one 8-wave workgroup per CU
-  const int max_splits = cdiv(ntiles, 16);                // at least 16 tiles per workgroup: below that the slab of its 64x64x9 block outweighs the parallelism (RSP N=128: +4 % step)
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  const int tps = cdiv(ntiles, splits);
-  splits = cdiv(ntiles, tps);
+  int tps, ntiles;
+  const int splits = wh_splits(a, TW, KH, &tps, &ntiles);
   const int pitch = BF ? (TW == 16 ? 24 : 16) : TW + 2;
   const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
   if (nseg > 8 || (a.seg_images > 0 && (a.N % a.seg_images != 0 || a.seg_images % NI != 0))) return hipErrorInvalidValue;
   const size_t lds = (size_t)KH * (128 * KH + NI * 10 * pitch) * 64 * sizeof(T) + 512 * nseg;     // NBUF = KH buffers of (KH dY halves + halo)
-  (void)HP;
   auto kern = wgrad3x3_halo_kernel<T, TW, KH>;
   static std::atomic<bool> attr_done{false};
   if (!attr_done) {
@@ -488,6 +499,11 @@ static hipError_t launch_wh(const WgradArgs& a, hipStream_t st) {
   if (splits > 1) {
     slabs = reinterpret_cast<f32x4_t*>(stream_scratch(st, (size_t)gx * gy * splits * 36 * 256 * KH * sizeof(f32x4_t)));
     if (!slabs) return hipErrorOutOfMemory;        // (no atomic path to fall back to: its summation order would differ)
+  }
+  if (KH == 2 && BF && wgrad_dma_ok(Elem<T>::DT, a, splits)) {      // operands by LDS DMA, same tiles / slabs / bits (wgrad_dma.hip)
+    hipError_t e = launch_wgrad_dma(a, TW, tps, ntiles, splits, slabs, st);
+    if (e != hipSuccess) return e;
+    return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, 9, KH, st);
   }
   hipLaunchKernelGGL(kern, dim3(gx * gy * splits), dim3(256 * KH), lds, st, a, tps, ntiles, slabs);
   if (slabs) return launch_wgrad_fold(slabs, a.dw, a.C, gx, gy, splits, 9, KH, st);

@@ -31,7 +31,8 @@ def _chk(*ts):
                 raise L.SslcrError("sslcr kernels need contiguous tensors")
 
 
-last_conv_kernel = ""       # kernel instance the most recent conv2d() launched (rocprofv3 spelling), for tests / profiles
+last_conv_kernel = ""        # kernel instance the most recent conv2d() launched (rocprofv3 spelling), for tests / profiles
+last_wgrad_kernel = ""       # ... and the most recent conv2d_wgrad()
 
 
 def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bias=None, residual=None, relu=False,
@@ -150,6 +151,8 @@ def conv2d_wgrad(x, dy, dw, R, S, stride, pad, *, in_scale=None, in_shift=None, 
     assert dw.shape == (K, R, S, C) and dw.dtype == torch.float32
     d = L.WgradDesc(L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(in_scale), L.ptr(in_shift), int(in_relu),
                     N, H, W, C, K, R, S, stride, pad, OH, OW, int(seg_images), C if seg_images else 0)
+    global last_wgrad_kernel
+    last_wgrad_kernel = L.lib().sslcr_conv2d_wgrad_kernel_name(_dt(x), d).decode()
     L.check(L.lib().sslcr_conv2d_wgrad(_dt(x), d, L.stream_ptr()))
 
 

@@ -261,6 +261,28 @@ def test_conv_s2_wgrad(shape):
     close(dw.cpu() - base, want, 3e-3, "stride-2 wgrad")
 
 
+@pytest.mark.parametrize("xform", [False, True])
+@pytest.mark.parametrize("shape", [(5, 32, 32, 128, 128), (3, 16, 48, 64, 256), (40, 16, 16, 256, 256), (70, 8, 8, 128, 384), (34, 8, 16, 192, 128), (36, 16, 8, 64, 128)])
+def test_conv_wgrad_dma(shape, xform):
+    """3x3 / 1 weight gradient with the operands staged by LDS DMA (wgrad3x3_dma_kernel, bf16, 128-kout blocks, several pixel splits;
+    what the engine launches for layers 2-4): 16-wide and 8-wide tiles (whole 8x8 images, two tiles per image row), image-border
+    tiles whose halo is padding from the buffer range check, 1-4 cin blocks x 1-3 kout blocks, the halo by DMA (no producer
+    transform) and register-staged with the producer's BatchNorm + ReLU; accumulation into a non-zero dW."""
+    K = _k()
+    N, H, W, C, Ko = shape
+    x = q(rnd(71, (N, H, W, C)), 1)
+    dy = q(rnd(72, (N, H, W, Ko)), 1)
+    sc, sh = rnd(73, (C,)).abs() + 0.5, rnd(74, (C,))
+    base = rnd(75, (Ko, 3, 3, C))
+    dw = base.clone().to(DEV)
+    kw = dict(in_scale=sc.to(DEV), in_shift=sh.to(DEV), in_relu=True) if xform else {}
+    K.conv2d_wgrad(to_dev(x, 1), to_dev(dy, 1), dw, 3, 3, 1, 1, **kw)
+    tw = 16 if W % 16 == 0 else 8
+    assert K.last_wgrad_kernel == f"sslcr::wgrad3x3_dma_kernel<{tw}, {'true' if xform else 'false'}>", K.last_wgrad_kernel
+    xt = q(F.relu(x * sc + sh), 1) if xform else x
+    close(dw.cpu() - base, R.conv_wgrad(xt, dy, (Ko, 3, 3, C), 1, 1), 3e-3, "DMA-form wgrad")
+
+
 @pytest.mark.parametrize("shape", [(6, 64, 64, 64, 128), (9, 32, 32, 128, 256), (70, 64, 64, 64, 128), (3, 32, 64, 256, 384), (130, 32, 32, 128, 256)])
 def test_conv_s2_dgrad(shape):
     """input gradient of the 3x3 / 2 conv, the four output-parity classes in one pass over dY (conv_s2d_kernel, bf16; the par4
