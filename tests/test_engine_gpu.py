@@ -78,7 +78,8 @@ def yard16(name):
     sums) are sums of partly cancelling rounding errors, so they get 5 x the emulated figure (losses floored at 1e-4, where the
     emulation's own cancellation is luck); the element-wise feature comparison gets 2 x."""
     y = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_yard.npz"))
-    return {"ret": [5 * max(float(e), 1e-4) for e in y[f"{name}/ret_err"]], "rowl2": 5 * float(y[f"{name}/feats_rowl2_err"][0]),
+    return {"ret": [5 * max(float(e), 1e-4) for e in y[f"{name}/ret_err"]] if f"{name}/ret_err" in y.files else [],
+            "rowl2": 5 * float(y[f"{name}/feats_rowl2_err"][0]),
             "colsum": 5 * float(y[f"{name}/feats_colsum_err"][0]), "head": 2 * float(y[f"{name}/feats_err"][0])}
 
 
@@ -180,7 +181,7 @@ def test_backbone_forward_vs_reference_stages(mode, dtype):
 def test_forward_only_config2_full_size_vs_reference(mode, dtype):
     """BASELINE config 2 at its own size -- ResNet18 forward-only, N = 256 images of 256x256 -- against reductions of the reference
     module's own output (tests/golden/make_golden.py:gen_fwd_full): eval mode (BatchNorm folded into the conv packs, the teacher /
-    validate() path) and train mode (batch statistics, x3 running-stat replay).  fp32: 1e-3; bf16: 2 x the measured error."""
+    validate() path) and train mode (batch statistics, x3 running-stat replay).  fp32: 1e-3; bf16: 2 x the measured error, never above yard16()'s multiples of the emulated bf16-storage error."""
     _engine(dtype)
     g = load_golden("fwd_full")
     model, _ = build("finetune", "finetune", 1, True)
@@ -190,9 +191,10 @@ def test_forward_only_config2_full_size_vs_reference(mode, dtype):
     torch.cuda.synchronize()
     f = feats.cpu().double()
     assert tuple(f.shape) == (256, 768)
-    near(f"fwd_full/{mode}/feats_rowl2", dtype, rel_err(f.norm(dim=1), g[f"fwd_full/{mode}/feats_rowl2"]), 1e-3, 6e-2)
-    near(f"fwd_full/{mode}/feats_colsum", dtype, rel_err(f.sum(0), g[f"fwd_full/{mode}/feats_colsum"]), 1e-3, 6e-2)
-    near(f"fwd_full/{mode}/feats_head", dtype, rel_err(feats[:4].cpu(), g[f"fwd_full/{mode}/feats_head"]), 1e-3, 6e-2)
+    y16 = yard16(f"fwd_full/{mode}")          # bf16 ceilings: multiples of the emulated bf16-storage error of this very forward
+    near(f"fwd_full/{mode}/feats_rowl2", dtype, rel_err(f.norm(dim=1), g[f"fwd_full/{mode}/feats_rowl2"]), 1e-3, y16["rowl2"])
+    near(f"fwd_full/{mode}/feats_colsum", dtype, rel_err(f.sum(0), g[f"fwd_full/{mode}/feats_colsum"]), 1e-3, y16["colsum"])
+    near(f"fwd_full/{mode}/feats_head", dtype, rel_err(feats[:4].cpu(), g[f"fwd_full/{mode}/feats_head"]), 1e-3, y16["head"])
     if mode == "train":
         sd = model.state_dict()
         for k in ("model.bn1.running_mean", "model.bn1.running_var", "model.layer3.0.downsample.1.running_mean",
@@ -451,8 +453,8 @@ def test_rsp_full_size_step_vs_reference(dtype):
     images of 256x256 through the shared TripletNet backbone, 6-way CE, SGD-Nesterov) against reductions of the reference's
     own iteration: loss / accuracy, feature row norms and column sums, post-step snapshot, and every parameter gradient
     through its L2 norm and a seeded +-1 projection, against the float64 run of the same iteration.  fp32: 1e-3 on loss/features,
-    gradients within max(3e-3, 3 x the reference's own fp32 error); bf16: 6e-2 on loss, 0.2 on features, gradients within
-    2 x / 3.5 x the emulated bf16-storage error + 0.05 (oracle/bf16_emul.py)."""
+    gradients within max(3e-3, 3 x the reference's own fp32 error); bf16: loss / features within yard16()'s multiples of the emulated
+    bf16-storage error, gradients within 2 x / 3.5 x the emulated bf16-storage error + 0.05 (oracle/bf16_emul.py)."""
     from ssl_cr_histo_amd import steps
     eng = _engine(dtype)
     name = "rsp_full"
@@ -464,12 +466,13 @@ def test_rsp_full_size_step_vs_reference(dtype):
     a = ns(tile_h=c["hw"], tile_w=c["hw"])
     ret = steps.rsp_train(a, model, cls, C.rsp_batches(name), torch.nn.CrossEntropyLoss(), opt, 1)
     ts, tf, tp = TOLS[dtype]
-    near(f"{name}/ret0", dtype, relx(ret[0], g[f"{name}/ret"][0]), ts, ts)
+    y16 = yard16(name)
+    near(f"{name}/ret0", dtype, relx(ret[0], g[f"{name}/ret"][0]), ts, y16["ret"][0])
     f = ret[2].cpu().double()
     assert list(f.shape) == list(g[f"{name}/feats_shape"])
-    near(f"{name}/feats_rowl2", dtype, rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]), tf, 0.2)
-    near(f"{name}/feats_colsum", dtype, rel_err(f.sum(0), g[f"{name}/feats_colsum"]), tf, 0.2)
-    near(f"{name}/feats_head", dtype, rel_err(ret[2][:4].cpu(), g[f"{name}/feats_head"]), tf, 0.2)
+    near(f"{name}/feats_rowl2", dtype, rel_err(f.norm(dim=1), g[f"{name}/feats_rowl2"]), tf, y16["rowl2"])
+    near(f"{name}/feats_colsum", dtype, rel_err(f.sum(0), g[f"{name}/feats_colsum"]), tf, y16["colsum"])
+    near(f"{name}/feats_head", dtype, rel_err(ret[2][:4].cpu(), g[f"{name}/feats_head"]), tf, y16["head"])
     assert torch.equal(ret[3].cpu(), torch.from_numpy(g[f"{name}/targets"]))
     if dtype == "fp32":
         assert abs(ret[1] - g[f"{name}/ret"][1]) <= 100.0 / c["b"] + 1e-9      # accuracy in percent: at most one flipped prediction
@@ -551,11 +554,20 @@ def test_gradients_vs_oracle(kind, dtype):
         lt = OM.classifier_forward(pt, OM.finetune_forward(pt, bn_t, u_w.float(), False, True))
     g32, logits, loss = B.ssl_cr_grads(kind, ps, x.float(), y, u_s.float(), lt, lam, emulate=False)
     got = r["losses"].cpu()
-    near(f"grads_vs_oracle/{kind}/loss", dtype, relx(got[0], loss), 1e-3, 6e-2)
-    near(f"grads_vs_oracle/{kind}/logits", dtype, rel_err(r["logits"].cpu(), logits), 1e-3, 6e-2)
-    near(f"grads_vs_oracle/{kind}/logits_t", dtype, rel_err(r["logits_t"].cpu(), lt), 1e-3, 6e-2)
+    c_loss = c_logits = c_lt = 6e-2
     if dtype == "bf16":
+        # independent ceilings: the same step on the CPU with bf16 STORAGE emulated in the student (train mode) and in the teacher
+        # (BatchNorm folded into bf16 filters), oracle/bf16_emul.py -- 5 x its loss error (a scalar: partly cancelling), 2 x its
+        # element-wise logit errors, never above the old flat 6e-2
+        lt16 = B.teacher_logits(pt, bn_t, u_w.float(), True)
+        _, logits16, loss16 = B.ssl_cr_grads(kind, ps, x.float(), y, u_s.float(), lt16, lam, emulate=True)
+        c_loss = min(c_loss, 5 * max(relx(loss16, loss), 1e-3))
+        c_logits = min(c_logits, 2 * float(rel_err(logits16, logits)))
+        c_lt = min(c_lt, 2 * float(rel_err(lt16, lt)))
         g16, _, _ = B.ssl_cr_grads(kind, ps, x.float(), y, u_s.float(), lt, lam, emulate=True)
+    near(f"grads_vs_oracle/{kind}/loss", dtype, relx(got[0], loss), 1e-3, c_loss)
+    near(f"grads_vs_oracle/{kind}/logits", dtype, rel_err(r["logits"].cpu(), logits), 1e-3, c_logits)
+    near(f"grads_vs_oracle/{kind}/logits_t", dtype, rel_err(r["logits_t"].cpu(), lt), 1e-3, c_lt)
     rows, bad = [], []
     for i, k in enumerate(ps.keys()):
         ref = g32[k].double()

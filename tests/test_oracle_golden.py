@@ -357,3 +357,13 @@ def test_bf16_yardstick_is_pinned_to_the_reference(name):
     assert np.allclose(y[f"{name}/ret_bf16emul"], y[f"{name}/ret_f64"], rtol=5e-3, atol=0)
     assert int(y[f"{name}/argmax_flips"][0]) == 0
     assert 1e-4 < float(y[f"{name}/teacher_logits_err"][0]) < 5e-3 and 1e-3 < float(y[f"{name}/feats_err"][0]) < 2e-2
+
+
+def test_bf16_yardstick_rsp_and_forward_only_are_pinned_to_the_reference():
+    """the float64 runs behind the rsp_full / fwd_full yardsticks reproduce the reference's own loss and feature row norms"""
+    y = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_yard.npz"))
+    assert abs(float(y["rsp_full/ret_f64"][0]) - load_golden("rsp_full")["rsp_full/ret"][0]) <= 2e-6 * float(y["rsp_full/ret_f64"][0])
+    g = load_golden("fwd_full")
+    for mode in ("eval", "train"):
+        assert rel_err(torch.from_numpy(y[f"fwd_full/{mode}/feats_rowl2_f64"]), g[f"fwd_full/{mode}/feats_rowl2"]) < 2e-6
+        assert 1e-3 < float(y[f"fwd_full/{mode}/feats_err"][0]) < 2e-2
