@@ -12,6 +12,9 @@ OUT = os.path.join(ROOT, "tests", "measured_errors.json")
 def main(argv):
     merge = "--merge" in argv
     files = [a for a in argv if not a.startswith("--")]
+    if not files:                                # (nothing to fold: never replace the table by an empty one)
+        print(__doc__)
+        return
     table = {}
     if merge and os.path.exists(OUT):
         table = json.load(open(OUT))
