@@ -13,8 +13,9 @@
 //   * behind an LDS DMA the compiler puts `s_waitcnt vmcnt(0)` in front of every ds_read_b64_tr_b16 INTRINSIC, so the transpose
 //     reads are inline asm and the LDS counter is kept by hand: the two reads of tap t + 1 are issued before the four MFMAs of
 //     tap t, which wait with lgkmcnt(2).
-// The DMA of tile t + 1 is requested before tile t's MFMA loop into the other buffer; requests are issued dY first, then the
-// halo, and (XF) the register loads last, so that the wait the compiler puts in front of the halo conversion covers the DMA too.
+// The DMA of tile t + 1 goes into the other buffer while tile t computes: a request costs its wave some hundred cycles of issue, so a
+// wave's nine requests are spread over the odd taps of the first half of the MFMA loop (all nine in front of the loop: +0.14 ms per
+// step); `s_waitcnt vmcnt(0)` + a bare barrier end the tile.
 #include <stdlib.h>
 
 #include <atomic>
@@ -133,7 +134,7 @@ __device__ __forceinline__ void wd_prologue_b(u32x2_t (&bf)[D + 1][2], const uin
 }
 }  // namespace
 
-template <int TW, bool XF, int D, bool ADBL, bool STAG>
+template <int TW, bool XF>
 __global__ __launch_bounds__(512, 2) void wgrad3x3_dma_kernel(const WgradArgs a, int tiles_per_split, int ntiles, f32x4_t* partials, int stagger) {
   using T = bf16_t;
   constexpr int EPC = 8, RB = WD_RB, CPR = 8;
@@ -328,7 +329,9 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_dma_kernel(const WgradArgs a,
     const int hp = hpix(pl) + sx;
     boff[sx] = wd_lds(smem) + YBUF + hp * RB + ((wave ^ wd_swz(hp)) << 5) + (li & 3) * 8;
   }
-  const bool spread = STAG && stagger;
+  constexpr int D = 1;                         // B fragments one tap ahead (two or three taps, and the next depth step's A fragments
+  constexpr bool ADBL = false;                 // at tap 4, measured the same: NOTES r05)
+  const bool spread = stagger != 0;
   prepare_dma(t_begin, 0, true);
   if constexpr (XF) {
     load_regs(t_begin);
@@ -379,12 +382,12 @@ bool wgrad_dma_ok(int dtype, const WgradArgs& a, int splits) {
   return px * a.K * 2 < (1ll << 31) && px * a.C * 2 < (1ll << 31);
 }
 
-template <int TW, bool XF, int D, bool ADBL, bool STAG = true>
+template <int TW, bool XF>
 static hipError_t launch_wd_t(const WgradArgs& a, int tps, int ntiles, int splits, f32x4_t* slabs, hipStream_t st) {
   constexpr int NI = 128 / (8 * TW), PITCH = TW == 16 ? 24 : 16;
   const int nseg = a.seg_images > 0 ? a.N / a.seg_images : 1;
   const size_t lds = (size_t)2 * (256 + NI * 10 * PITCH) * 128 + 512 * nseg;
-  auto kern = wgrad3x3_dma_kernel<TW, XF, D, ADBL, STAG>;
+  auto kern = wgrad3x3_dma_kernel<TW, XF>;
   static std::atomic<bool> attr_done{false};
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -400,14 +403,8 @@ static hipError_t launch_wd_t(const WgradArgs& a, int tps, int ntiles, int split
 hipError_t launch_wgrad_dma(const WgradArgs& a, int tw, int tps, int ntiles, int splits, void* slabs, hipStream_t st) {
   f32x4_t* s = reinterpret_cast<f32x4_t*>(slabs);
   const bool xf = a.in_scale != nullptr;
-  static const int depth = [] { const char* e = getenv("SSLCR_WG_DEPTH"); return e ? atoi(e) : 1; }();
-#define WD_GO(TW_, XF_) \
-  (depth >= 3 ? launch_wd_t<TW_, XF_, 3, true>(a, tps, ntiles, splits, s, st) \
-              : depth == 2 ? launch_wd_t<TW_, XF_, 2, true>(a, tps, ntiles, splits, s, st) \
-                           : launch_wd_t<TW_, XF_, 1, false>(a, tps, ntiles, splits, s, st))
-  if (tw == 16) return xf ? WD_GO(16, true) : WD_GO(16, false);
-  return xf ? WD_GO(8, true) : WD_GO(8, false);
-#undef WD_GO
+  if (tw == 16) return xf ? launch_wd_t<16, true>(a, tps, ntiles, splits, s, st) : launch_wd_t<16, false>(a, tps, ntiles, splits, s, st);
+  return xf ? launch_wd_t<8, true>(a, tps, ntiles, splits, s, st) : launch_wd_t<8, false>(a, tps, ntiles, splits, s, st);
 }
 
 }  // namespace sslcr
