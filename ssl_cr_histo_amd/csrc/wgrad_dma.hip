@@ -275,6 +275,8 @@ __global__ __launch_bounds__(512, 2) void wgrad3x3_dma_kernel(const WgradArgs a,
     const unsigned long long bad = edge & out;
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
+      // (measured and not kept here, same box: the branch-free form of wgrad_halo.hip -- 190-193 -> 197-203 us per launch --, and the
+      //  halo conversion of waves 0-3 moved in front of their MFMA loop so that SIMD partners convert at opposite ends of a tile: +-0)
       u32x4_t v = {0u, 0u, 0u, 0u};
       const bool ok = ((hvalid >> i) & 1u) && !((bad >> (4 * i)) & 0xfull);
       if (ok) v = ld16(xg + (size_t)(origin + rel_h[i]) * a.C * sizeof(T) + xbase);

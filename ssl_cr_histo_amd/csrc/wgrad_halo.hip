@@ -148,11 +148,11 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
     const unsigned long long bad = edge & out;                                   // entry i is padding iff any of its 4 bits is set
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-      u32x4_t v = {0u, 0u, 0u, 0u};
+      // branch-free: a padding entry loads the tile origin (a valid address) and is zeroed when staged (as `if (ok) v = load` every
+      // load was followed by its own s_waitcnt vmcnt(0), the merge of the two definitions: one exposed round trip per entry)
       const bool ok = ((hvalid >> i) & 1u) && !((bad >> (4 * i)) & 0xfull);
-      if (ok) v = ld16(xg + (size_t)(origin + rel_h[i]) * a.C * sizeof(T) + xbase);
-      else hin &= ~(1u << i);
-      hreg[i] = v;
+      hreg[i] = ld16(xg + (size_t)(origin + (ok ? rel_h[i] : 0)) * a.C * sizeof(T) + xbase);
+      if (!ok) hin &= ~(1u << i);
     }
   };
   // Bank swizzle of the bf16 tiles.  A transpose read presents, per 32 lanes, 8 pixel rows x 32 bytes at ONE column offset;
@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256 * KH, 2) void wgrad3x3_halo_kernel(const WgradA
       const int hni = hp / (HH * HWD), hrem = hp - hni * (HH * HWD);
       const int hpl = (hni * HH + hrem / HWD) * PITCH + hrem % HWD;      // pitched LDS pixel index
       u32x4_t v = hreg[i];
-      if (xform && ((hin >> i) & 1u)) {
+      if (!((hin >> i) & 1u)) {
+        v = u32x4_t{0u, 0u, 0u, 0u};              // padding
+      } else if (xform) {
         float f[EPC];
         Elem<T>::unpack(v, f);
 #pragma unroll
