@@ -57,11 +57,13 @@ def parse():
     ap.add_argument("--bn-sync", type=int, default=1, choices=[0, 1],
                     help="N>1: 1 = train-mode BatchNorm on global-batch statistics (RCCL all-reduce of per-channel sums, the "
                          "north-star form); 0 = per-replica statistics like the reference's nn.DataParallel (gradient buckets only)")
-    ap.add_argument("--aux-stream", type=int, default=0, choices=[0, 1],
-                    help="1 = teacher forward on a second HIP stream next to the student forward (about -2 %% step time); off by "
-                         "default because concurrent launches make the per-kernel durations of the roofline leg meaningless")
-    ap.add_argument("--wgrad-stream", type=int, default=0, choices=[0, 1],
-                    help="1 = backward's weight-gradient launches on a second HIP stream (measured neutral: 18.84 vs 18.76 ms/step)")
+    ap.add_argument("--aux-stream", type=int, default=1, choices=[0, 1],
+                    help="1 (default since round 6) = teacher forward on a second HIP stream next to the student forward.  The roofline "
+                         "leg runs the same steps SERIALISED (sslcr_profile forces both side streams off: a per-kernel duration "
+                         "measured under a concurrent launch says nothing about the kernel)")
+    ap.add_argument("--wgrad-stream", type=int, default=1, choices=[0, 1],
+                    help="1 (default since round 6) = backward's weight-gradient launches on a second HIP stream; bit-identical.  "
+                         "Same-box, round 6 (profiles/r06_streams_ab.txt): neither stream alone moves the step, both together -0.2 ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the other configurations (forward-only, RSP, frozen, fp32 parity, config 5)")
@@ -648,15 +650,19 @@ def run_rank(args, rank, world, device, eng, ranks, want_transport):
         if rank == 0:
             rows = eng.profile_table()      # per kernel template instance, sorted by total time
         eng.profile(False)
+    # the workload (modules, optimizer state, the engine nets' activations) goes into a holder that rank 0 empties before the side
+    # configurations run in their child processes: they are measured on an otherwise empty device, as in round 4
+    work = [step, keep]
+    del step, keep
     if rank == 0:
-        rank0_only_legs(args, world, out, rows, nprof, ms_per_step, keep)
+        rank0_only_legs(args, world, out, rows, nprof, ms_per_step, work)
         out["parity"] = parity_record(out)
         print(json.dumps(out), flush=True)
-    del keep
+    work.clear()
     barrier()                               # the final barrier of the job: every rank arrives here, whatever rank 0 did on its own
 
 
-def rank0_only_legs(args, world, out, rows, nprof, ms_per_step, keep):
+def rank0_only_legs(args, world, out, rows, nprof, ms_per_step, work):
     """Everything only rank 0 does.  NOTHING here may step the engine or call a collective when world > 1: the legs that run the
     workload again (counter passes, CPU baseline, side configurations) are child processes and are world == 1 only."""
     if not args.no_roofline:
@@ -745,6 +751,9 @@ def rank0_only_legs(args, world, out, rows, nprof, ms_per_step, keep):
             out["cpu_baseline"]["host"]["concurrent_with_gpu_legs"] = False
     if world == 1 and not args.no_also and args.workload == "ssl_cr" and args.dtype == "bf16":
         # the other BASELINE.json configurations on the same box (short runs: they are records, not the headline)
+        import gc
+        work.clear()                    # world == 1: nothing steps this workload again
+        gc.collect()
         torch.cuda.empty_cache()
         out["also"] = also_records(args)
 

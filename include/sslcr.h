@@ -29,6 +29,7 @@ extern "C" {
 #define SSLCR_BF16 1
 #define SSLCR_FP8 2   /* engine mode only (sslcr_create): bf16 storage and backward, fp8 e4m3 forward for the eligible 3x3 convs */
 
+/* the library round (6 here).  ABI notes below name the version a behaviour changed in: 4 = sslcr_bn_bwd_reduce overwrites its sums. */
 int sslcr_version(void);
 const char* sslcr_last_error(void);
 
@@ -178,6 +179,10 @@ typedef struct sslcr_bn_finalize_desc {
      per channel of ONE segment).  With sums_out (rows -> sums only) segment s writes sums_out + s * seg_stride doubles.  Not
      with sums_in. */
   int nseg, seg_stride;
+  /* library version >= 6.  NULL: two launches (row reduction, finalize).  Else ceil(C / 32) ints, ZERO before the first call and
+     left at zero by every call, not shared with a launch that may run concurrently: the row reduction's last workgroup per
+     channel block finalizes it in the same launch (same arithmetic, same bits, one launch less per BatchNorm). */
+  int* tickets;
 } sslcr_bn_finalize_desc;
 int sslcr_bn_finalize(const sslcr_bn_finalize_desc* d, void* stream);
 
@@ -377,8 +382,9 @@ int sslcr_comm_init_virtual(sslcr_ctx* ctx, sslcr_vcomm* v, int rank);
  * semantics of the reference's nn.DataParallel replicas -- and only the gradient buckets are exchanged. */
 int sslcr_set_bn_sync(sslcr_ctx* ctx, int on);
 /* on: sslcr_step_ssl_cr runs the (frozen, eval-mode) teacher forward on a second HIP stream next to the student forward --
- * the workgroups of one fill the tail rounds of the other's kernels (measured -0.4 ms of a 20.4 ms step).  Off by default:
- * concurrent launches share the CUs, which makes per-kernel durations (HIP events and rocprofv3 alike) meaningless as a
+ * the workgroups of one fill the tail rounds of the other's kernels (measured -0.4 ms of a 20.4 ms step in round 1; in round 6,
+ * 15.4 ms step: +-0 alone, -0.2 ms together with sslcr_set_wgrad_stream).  Off by default in the library; bench.py turns it on.
+ * Forced off while sslcr_profile() is on: concurrent launches share the CUs, which makes per-kernel durations meaningless as a
  * statement about the kernel, and bench.py's roofline is built from those. */
 int sslcr_set_aux_stream(sslcr_ctx* ctx, int on);
 /* on: in backward the weight-gradient launches run on a second HIP stream behind an event -- they depend only on a

@@ -38,7 +38,7 @@ BnFinalizeDesc = _S("BnFinalizeDesc", [("partials", vp), ("rows", i32), ("C", i3
                                        ("beta", vp), ("scale", vp), ("shift", vp), ("mean", vp), ("invstd", vp),
                                        ("running_mean", vp), ("running_var", vp), ("num_batches_tracked", vp),
                                        ("momentum", f32), ("eps", f32), ("replay", i32), ("sums_out", vp),
-                                       ("sums_in", vp), ("stage", vp), ("nseg", i32), ("seg_stride", i32)])
+                                       ("sums_in", vp), ("stage", vp), ("nseg", i32), ("seg_stride", i32), ("tickets", vp)])
 BnActDesc = _S("BnActDesc", [("x", vp), ("scale", vp), ("shift", vp), ("res", vp), ("rscale", vp), ("rshift", vp),
                              ("y", vp), ("pixels", sz), ("C", i32), ("relu", i32), ("nseg", i32), ("seg_stride", i32), ("ybits", vp)])
 PoolFwdDesc = _S("PoolFwdDesc", [("x", vp), ("scale", vp), ("shift", vp), ("y", vp), ("argmax", vp)] +

@@ -48,10 +48,13 @@ __global__ __launch_bounds__(256) void bn_reduce_rows_kernel(const float* __rest
 }
 
 // stage 2 (+ finalize): one thread per channel; with segments (a.nseg > 1) the thread finalizes them one after the other, so the
-// running statistics see the updates in segment order -- the order of the reference's successive forward calls
-__global__ void bn_finalize_kernel(const double* __restrict__ stage, int splits, const BnFinalizeArgs a) {
+// running statistics see the updates in segment order -- the order of the reference's successive forward calls.
+// cb = channel block (32 channels), 256 threads = 32 channels x 8 lanes.  SC1: the stage rows were published by OTHER workgroups of
+// this launch with write-through stores (bn_reduce_finalize_kernel): read them past this CU's L1
+template <bool SC1>
+__device__ __forceinline__ void bn_finalize_block(const double* __restrict__ stage, int splits, const BnFinalizeArgs& a, int cb) {
   // 8 lanes per channel share the split rows (a serial loop over 32 splits is 64 dependent loads = 10 us per BatchNorm)
-  const int c = blockIdx.x * (blockDim.x / 8) + (threadIdx.x >> 3);
+  const int c = cb * 32 + (threadIdx.x >> 3);
   const int part = threadIdx.x & 7;
   const int cc = c < a.C ? c : a.C - 1;
   const int nseg = a.nseg > 1 ? a.nseg : 1;
@@ -66,8 +69,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stage, int splits,
     } else {
       const double* stz = stage + (size_t)z * splits * 2 * a.C;
       for (int i = part; i < splits; i += 8) {
-        s += stz[((size_t)i * 2) * a.C + cc];
-        ss += stz[((size_t)i * 2 + 1) * a.C + cc];
+        const double* p0 = stz + ((size_t)i * 2) * a.C + cc;
+        if (SC1) {
+          s += __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ss += __hip_atomic_load(p0 + a.C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          s += p0[0];
+          ss += p0[a.C];
+        }
       }
 #pragma unroll
       for (int m = 1; m < 8; m <<= 1) { s += __shfl_xor(s, m); ss += __shfl_xor(ss, m); }
@@ -103,8 +112,78 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stage, int splits,
     if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += (int64_t)a.replay * nseg;
   }
 }
+__global__ void bn_finalize_kernel(const double* __restrict__ stage, int splits, const BnFinalizeArgs a) {
+  bn_finalize_block<false>(stage, splits, a, blockIdx.x);
+}
 
+// Both stages in ONE launch (a.tickets != nullptr; round 6): the grid and every thread's arithmetic are bn_reduce_rows_kernel's, and
+// the workgroup that arrives LAST at its channel block's ticket (splits x nseg arrivals) runs bn_finalize_block for the block --
+// the same lanes, loads and adds as the second launch: the same bits, one launch (and one dependent launch boundary) less per
+// BatchNorm.  Cross-workgroup visibility without an L2 write-back (a release fence at agent scope is `buffer_wbl2`, and the conv
+// that has just run left megabytes of dirty output in every XCD's L2 -- what made the round-2 ticket form slower than two launches):
+// the 64 stage values of a workgroup are published with write-through (sc1) stores, the publishing wave waits vmcnt(0) before its
+// lane 0 takes the ticket, and the last arriver reads the stage with sc1 loads (past its L1; no XCD's L2 can hold an older copy of
+// these lines: kernel start invalidated them and nobody reads them before the last ticket).  The ticket word is left at 0.
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* __restrict__ part, int rows, double* __restrict__ stage, int splits,
+                                                                 const BnFinalizeArgs a) {
+  __shared__ double sm[2][8][32];
+  __shared__ int s_last;
+  const int C = a.C;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int rl = threadIdx.x >> 5;
+  const int per = (rows + splits - 1) / splits;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  part += (size_t)blockIdx.z * rows * 2 * C;
+  double* out = stage + (size_t)blockIdx.z * splits * 2 * C;
+  double s = 0.0, ss = 0.0;
+  if (c < C) {
+    int r = r0 + rl;
+    for (; r + 8 < r1; r += 16) {               // two rows in flight per trip
+      const float* p = part + (size_t)r * 2 * C;
+      const float* q = p + (size_t)16 * C;
+      const float a0 = p[c], a1 = p[C + c], b0 = q[c], b1 = q[C + c];
+      s += (double)a0 + (double)b0;
+      ss += (double)a1 + (double)b1;
+    }
+    for (; r < r1; r += 8) {
+      const float* p = part + (size_t)r * 2 * C;
+      s += (double)p[c];
+      ss += (double)p[C + c];
+    }
+  }
+  sm[0][rl][threadIdx.x & 31] = s;
+  sm[1][rl][threadIdx.x & 31] = ss;
+  __syncthreads();
+  if (threadIdx.x < 64) {                       // wave 0: publish, drain, ticket
+    const int which = threadIdx.x >> 5, cc = threadIdx.x & 31;
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += sm[which][i][cc];
+    const int ch = blockIdx.x * 32 + cc;
+    if (ch < C) __hip_atomic_store(&out[((size_t)blockIdx.y * 2 + which) * C + ch], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0) {
+      const int total = (int)(gridDim.y * gridDim.z);
+      const int old = __hip_atomic_fetch_add(a.tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = old == total - 1;
+      if (old == total - 1) __hip_atomic_store(a.tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    }
+  }
+  __syncthreads();
+  if (!s_last) return;
+  bn_finalize_block<true>(stage, splits, a, blockIdx.x);
+}
+
+static hipError_t launch_bn_finalize_once(const BnFinalizeArgs& a, hipStream_t st);
 hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
+  // SSLCR_BN_REPEAT=n (measurement only: the running statistics take n updates): the launch(es) n times back to back -- the step
+  // time difference / ((n - 1) x launches) is what one BatchNorm finalize costs IN the stream, without a profiler's per-kernel overhead
+  static const int rep = [] { const char* e = getenv("SSLCR_BN_REPEAT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v; }();
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < rep && e == hipSuccess; ++i) e = launch_bn_finalize_once(a, st);
+  return e;
+}
+static hipError_t launch_bn_finalize_once(const BnFinalizeArgs& a, hipStream_t st) {
   constexpr int SPLITS = 32;
   double* stage = a.stage;
   int splits = 0;
@@ -115,6 +194,13 @@ hipError_t launch_bn_finalize(const BnFinalizeArgs& a, hipStream_t st) {
     splits = rows / 32;                         // >= 4 dependent row loads per thread before it is worth another block row
     if (splits > SPLITS) splits = SPLITS;
     if (splits < 1) splits = 1;
+    // OFF by default (round 6, profiles/r06_bn_one_launch_ab.txt): in the stream a finalize pair costs 4.35 us (two launches) and the
+    // ticketed launch 5.9 us -- the write-through publish, the returned atomic and the sc1 reads are dearer than a launch boundary
+    static const bool one = [] { const char* e = getenv("SSLCR_BN_ONE_LAUNCH"); return e && atoi(e) != 0; }();
+    if (a.tickets && one) {
+      hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(a.C, 32), splits, nseg), dim3(256), 0, st, a.partials, rows, stage, splits, a);
+      return hipGetLastError();
+    }
     hipLaunchKernelGGL(bn_reduce_rows_kernel, dim3(cdiv(a.C, 32), splits, nseg), dim3(256), 0, st, a.partials, rows, a.C, stage, splits);
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a.C, 32)), dim3(256), 0, st, stage, splits, a);

@@ -30,7 +30,7 @@ using namespace sslcr;
 
 extern "C" {
 
-int sslcr_version(void) { return 1; }
+int sslcr_version(void) { return 6; }      // = the build round; the ABI notes in include/sslcr.h name the version a behaviour changed in
 const char* sslcr_last_error(void) { return g_err; }
 
 int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream) {

@@ -182,6 +182,7 @@ struct sslcr_ctx {
   DevBuf small;       // bn stage/sums, unit scale/shift
   double* bn_stage = nullptr;
   double* bn_sums = nullptr;
+  int* bn_tickets = nullptr;      // sslcr_bn_finalize_desc.tickets: 16 zeroed ints (every BatchNorm finalize of this context runs on one stream at a time)
   // BatchNorm-backward sums: every reduce pass of one backward takes its own [2][2][512]-double slot of this ring (the pass
   // overwrites it with the ordered sum of its workgroups' rows: nothing to clear)
   DevBuf bn_ring;
@@ -244,6 +245,8 @@ __global__ void vsum_kernel(T* dst, VSrc src, int W, size_t n) {
     dst[i] = s;
   }
 }
+
+std::atomic<int> g_live_ctx{0};     // contexts between sslcr_create and sslcr_destroy (see sslcr_destroy)
 
 inline bool sharded(const sslcr_ctx* c) { return c->comm != nullptr || c->vcomm != nullptr; }
 
@@ -551,6 +554,7 @@ int finalize_bn(sslcr_net* n, const BnL& bn, const float* partials, int rows, do
   if (n->f8_calib_pass) { a.running_mean = nullptr; a.running_var = nullptr; a.num_batches_tracked = nullptr; }
   a.momentum = 0.1f; a.eps = 1e-5f; a.replay = replay;
   a.stage = c->bn_stage;
+  a.tickets = c->bn_tickets;
   if (sharded(c) && c->bn_sync) {
     // global-batch statistics: reduce rows -> [2][C] sums, all-reduce, finalize from the sums
     BnFinalizeArgs r = a;
@@ -714,6 +718,7 @@ int forward_blocks(sslcr_net* n, PassState& ps, int N, int H, int W, int replay,
       paired = !use_fp8(c, B.c1, a1) && conv_s2_pair_ok(dt, t1, td);
     }
     if (paired) {
+      if (segs && (!conv_segments_ok(dt, a1) || !conv_segments_ok(dt, ad))) return fail("forward_blocks: the paired stride-2 launch has no segment form here");
       rows = conv_partials_rows(a1);
       const size_t rb = (size_t)rows * 2 * a1.K * sizeof(float);
       TRYI(c->partials.ensure(2 * rb));
@@ -1026,7 +1031,7 @@ int bn_bwd_begin(sslcr_net* n, const BnL& bn, const BnSaved& sv, const void* dy,
     // the dgrad that produced dy already left partial rows of (sum g, sum g (x - mean)) (sslcr_conv_desc.mask_x): rows -> sums
     BnFinalizeArgs r;
     memset(&r, 0, sizeof(r));
-    r.partials = sum_rows; r.rows = n_sum_rows; r.C = bn.C; r.stage = c->bn_stage; r.sums_out = sums;
+    r.partials = sum_rows; r.rows = n_sum_rows; r.C = bn.C; r.stage = c->bn_stage; r.sums_out = sums; r.tickets = c->bn_tickets;
     if (nseg > 1) { r.nseg = nseg; r.seg_stride = sslcr_ctx::kBnSlot; }
     TRY(launch_bn_finalize(r, st));
   } else if (!defer) {                              // (defer: the caller launches the reduce pass itself -- the two-BatchNorm form)
@@ -1548,14 +1553,17 @@ int sslcr_create(sslcr_ctx** out, int device, int dtype) {
   c->device = device; c->dtype = dtype == SSLCR_FP8 ? SSLCR_BF16 : dtype; c->fp8 = dtype == SSLCR_FP8;
   if (const char* e = getenv("SSLCR_FUSE_STEM_BWD")) c->fuse_stem_bwd = atoi(e) != 0;
   // bn_stage: [kMaxSeg][32][2][C] (sslcr_bn_finalize_desc.stage with segments)
-  if (c->small.ensure((size_t)kMaxSeg * 32 * 2 * 512 * sizeof(double) + 2 * 2 * 512 * sizeof(double) + 2 * 512 * sizeof(float)) != 0) { delete c; return -1; }
+  if (c->small.ensure((size_t)kMaxSeg * 32 * 2 * 512 * sizeof(double) + 2 * 2 * 512 * sizeof(double) + 2 * 512 * sizeof(float) + 64 * sizeof(int)) != 0) { delete c; return -1; }
   c->bn_stage = (double*)c->small.p;
   c->bn_sums = c->bn_stage + (size_t)kMaxSeg * 32 * 2 * 512;        // two [2][C] slots (bn2 + projection BatchNorm of a block share an all-reduce)
   c->ones = (float*)(c->bn_sums + 2 * 2 * 512);
   c->zeros = c->ones + 512;
+  c->bn_tickets = (int*)(c->zeros + 512);
+  TRY(hipMemset(c->bn_tickets, 0, 64 * sizeof(int)));
   TRY(launch_fill(c->ones, 512, 1.f, nullptr));
   TRY(launch_fill(c->zeros, 512, 0.f, nullptr));
   TRY(hipStreamSynchronize(nullptr));
+  g_live_ctx.fetch_add(1);
   *out = c;
   return 0;
 }
@@ -1581,7 +1589,9 @@ int sslcr_destroy(sslcr_ctx* c) {
     (void)hipEventDestroy(c->ev_done);
   }
   c->scratch.release(); c->partials.release(); c->small.release(); c->bn_ring.release();
-  stream_scratch_release();          // the per-stream fold scratch of the weight-gradient / BatchNorm-backward launches
+  // the per-stream fold scratch of the weight-gradient / BatchNorm-backward launches is process-global: freed with the LAST live
+  // context only -- another context's host thread (virtual ranks) may hold a slab pointer it has not launched with yet
+  if (g_live_ctx.fetch_sub(1) == 1) stream_scratch_release();
   delete c;
   return 0;
 }
@@ -1985,7 +1995,7 @@ int sslcr_step_ssl_cr(sslcr_net* te, sslcr_net* stn, const sslcr_ssl_cr_desc* d,
   // teacher: eval + no_grad (eval_BreastPathQ_SSL_CR.py:43-44,77-79) -- on the second stream when sslcr_set_aux_stream asked
   // for it (the per-kernel profiler records each launch on the stream it runs on)
   sslcr_ctx* c = stn->ctx;
-  const bool aux = c->use_aux && te->ctx == c;
+  const bool aux = c->use_aux && te->ctx == c && !c->prof.on;     // (per-kernel profiling: serialised, like the weight-gradient stream)
   hipStream_t tst = st;
   if (aux) {
     if (!c->aux_stream) {

@@ -265,7 +265,7 @@ def stem_wgrad_pool(x_nchw, dw, raw, scale, shift, mean, invstd, pool, *, x2=Non
 
 
 def bn_finalize(partials, count, gamma, beta, *, running_mean=None, running_var=None, nbt=None, momentum=0.1,
-                eps=1e-5, replay=1, nseg=1):
+                eps=1e-5, replay=1, nseg=1, one_launch=True):
     """partial rows [rows,2,C] -> (scale, shift, mean, invstd); running stats updated in place `replay` times.
     nseg > 1: the rows are nseg equal segments, the outputs are [nseg, C] (count = elements per channel of one segment)."""
     _chk(partials, gamma, beta, running_mean, running_var, nbt)
@@ -274,10 +274,14 @@ def bn_finalize(partials, count, gamma, beta, *, running_mean=None, running_var=
     shape = (nseg, Cn) if nseg > 1 else (Cn,)
     scale, shift, mean, invstd = (torch.empty(shape, dtype=torch.float32, device=dev) for _ in range(4))
     stage = torch.empty((max(nseg, 1), 32, 2, Cn), dtype=torch.float64, device=dev)
+    # one_launch: the ticketed form (row reduction + finalize in one launch); False: the two launches -- same bits
+    tickets = torch.zeros((Cn + 31) // 32, dtype=torch.int32, device=dev) if one_launch else None
     d = L.BnFinalizeDesc(L.ptr(partials), rows, Cn, float(count), L.ptr(gamma), L.ptr(beta), L.ptr(scale), L.ptr(shift),
                          L.ptr(mean), L.ptr(invstd), L.ptr(running_mean), L.ptr(running_var), L.ptr(nbt), momentum, eps,
-                         replay, None, None, L.ptr(stage), nseg if nseg > 1 else 0, Cn if nseg > 1 else 0)
+                         replay, None, None, L.ptr(stage), nseg if nseg > 1 else 0, Cn if nseg > 1 else 0, L.ptr(tickets))
     L.check(L.lib().sslcr_bn_finalize(d, L.stream_ptr()))
+    if tickets is not None:
+        assert int(tickets.abs().sum()) == 0, "sslcr_bn_finalize left a ticket word non-zero"
     return scale, shift, mean, invstd
 
 

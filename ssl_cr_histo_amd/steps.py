@@ -52,6 +52,8 @@ class _Meters:
             # W <= 256, so every partial sum of any reduction order is an exact fp32 integer (with base-4096 digits the cross-rank
             # sums of squares passed 2^24 and could round: a false mismatch at world >= 3)
             n = len(self.rows)
+            if self.world > 256:
+                raise RuntimeError("_Meters.meters(): the row-count header is exact in fp32 for world <= 256 only")
             if n >= 1 << 24:
                 raise RuntimeError("_Meters.meters(): more than 2^24 rows gathered between two reads")
             d = [float((n >> (8 * i)) & 255) for i in range(3)]

@@ -124,7 +124,12 @@ def test_conv_s2_pair(shape, mode):
     w3 = q(rnd(42, (Ko, 3, 3, C), 0.05), 1)
     w1 = q(rnd(43, (Ko, 1, 1, C), 0.1), 1)
     if mode == "train":
+        # (routing: sslcr_conv2d_s2_pair has no other kernel behind it -- kernels.conv2d_s2_pair raises where sslcr_conv2d_s2_pair_ok
+        #  says no; the single-conv train instance through the ordinary entry point is asserted by name below)
         y3, yd, s3, sd = K.conv2d_s2_pair(to_dev(x, 1), to_dev(w3, 1), to_dev(w1, 1), want_stats=True)
+        y3s, s3s = K.conv2d(to_dev(x, 1), to_dev(w3, 1), 2, 1, want_stats=True)
+        assert "conv_s2_kernel<false, false>" in K.last_conv_kernel, K.last_conv_kernel
+        assert torch.equal(y3s, y3) and torch.equal(s3s, s3)
         for y, st, w, (r, pad) in ((y3, s3, w3, (3, 1)), (yd, sd, w1, (1, 0))):
             want = R.conv_fwd(x, w, 2, pad)
             close(y, want, TOL[1], f"raw {r}x{r}")
@@ -142,6 +147,19 @@ def test_conv_s2_pair(shape, mode):
         y3s = K.conv2d(to_dev(x, 1), to_dev(w3, 1), 2, 1, bias=b3.to(DEV), relu=True)
         assert "conv_s2_kernel<false, true>" in K.last_conv_kernel, K.last_conv_kernel
         assert torch.equal(y3s, y3)
+
+
+def test_conv_s2_relu_without_bias():
+    """ReLU asked for WITHOUT a bias on a 3x3 / 2 shape the plane-gather kernel tiles: its output clamp lives in the EVAL
+    instance, which the bias selects -- so the descriptor must go to the gather kernel, which honours relu on its own"""
+    K = _k()
+    N, H, W, C, Ko = 6, 64, 64, 64, 128
+    x = q(rnd(46, (N, H, W, C)), 1)
+    w3 = q(rnd(47, (Ko, 3, 3, C), 0.05), 1)
+    y = K.conv2d(to_dev(x, 1), to_dev(w3, 1), 2, 1, relu=True)
+    assert "conv_dma_kernel" in K.last_conv_kernel, K.last_conv_kernel
+    close(y, R.conv_fwd(x, w3, 2, 1, relu=True), TOL[1], "relu without bias")
+    assert float(y.float().min()) >= 0.0
 
 
 @pytest.mark.parametrize("dtype", [0, 1])
@@ -257,6 +275,8 @@ def test_conv_s2_wgrad(shape):
     base = rnd(63, (Ko, 3, 3, C))
     dw = base.clone().to(DEV)
     K.conv2d_wgrad(to_dev(x, 1), to_dev(dy, 1), dw, 3, 3, 2, 1)
+    # routing: were wgrad_s2_ok() to start rejecting these shapes the gather kernel would serve them and pass the numbers below
+    assert K.last_wgrad_kernel == f"sslcr::wgrad_s2_kernel<{16 if OW % 16 == 0 else 8}>", K.last_wgrad_kernel
     want = R.conv_wgrad(x, dy, (Ko, 3, 3, C), 2, 1)
     close(dw.cpu() - base, want, 3e-3, "stride-2 wgrad")
 

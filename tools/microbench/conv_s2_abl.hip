@@ -1,3 +1,5 @@
+// MEASUREMENT COPY of ssl_cr_histo_amd/csrc/conv_s2.hip as it stood at the end of round 5, WITH the timing-only ablation switches
+// (S2_ABL_*: they change results) that tools/microbench/s2_phase_bench.hip / build_abl.sh compile in.  The product kernel carries none.
 // 3x3 / stride 2 / pad 1 NHWC convolution (ResNet18 layer{2,3}.0.conv1 via models/net.py:32,77) on 16x16 OUTPUT tiles, with the block's
 // 1x1 / stride 2 projection (downsample.0) riding in the same launch on a second accumulator set: the persistent, all-DMA form of
 // the stride-1 pipeline (conv_h16.hip) for the shapes the gather kernel (conv_dma.hip) served at 0.3-0.55 PF/s.
@@ -30,12 +32,20 @@
 // fragments double-buffered across the barriers.  Output stage: pack + store (+ BatchNorm partial sums by the row16_fold16 tree)
 // for the train forward, bias (+ ReLU) for the eval forward with the BatchNorm folded (EVAL instance).  bf16 only; the fp32 parity
 // mode and the shapes that are not 16x16-tileable stay on conv_dma.
-#include "kernels.hpp"
+#include "../../ssl_cr_histo_amd/csrc/kernels.hpp"
 
 namespace sslcr {
 
 #define S2_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#ifdef S2_ABL_NOBAR
+#define S2_BARRIER() asm volatile("" ::: "memory")      /* timing only */
+#else
 #define S2_BARRIER() asm volatile("s_barrier" ::: "memory")
+#endif
+
+#ifndef S2_ABL_MFMA_T
+#define S2_ABL_MFMA_T TK      /* phase bench: 0 compiles the MFMAs out */
+#endif
 #ifdef SSLCR_S2_PROF
 __device__ unsigned long long g_s2_prof[8][8];
 #define S2_T(v) const unsigned long long v = __builtin_readcyclecounter()
@@ -129,8 +139,14 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
         if (p17) { ridx = (qq * 241) >> 12; cidx = qq - 17 * ridx; }
         else { ridx = qq >> 4; cidx = qq & 15; }
         const bool pad = (top && ridx == 0) || (left && cidx == 0);
+#if defined(S2_ABL_CHEAP)           /* timing only: no address arithmetic */
+        const int voff = (grp * 64 + ln) * 16;
+#else
         const int voff = pad ? OOR : ridx * rstep + cidx * cstep + (((ln & 7) ^ (cidx & 7)) << 4);
+#endif
+#ifndef S2_ABL_NOHALO
         if (qq < rows) xd.load16(dst0 + grp * 1024, voff, soff);
+#endif
       }
     }
   };
@@ -152,6 +168,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
     const int soff = ds ? (k0 * a.C + slab * CE) * (int)sizeof(T) : ((k0 * 9 + tid9) * a.C + slab * CE) * (int)sizeof(T);
     const int kstep = (ds ? a.C : 9 * a.C) * (int)sizeof(T);
     char* dst0 = s_w + slot * WS + w * 1024;
+#ifndef S2_ABL_NOW
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (i * nw < 16) {
@@ -160,6 +177,7 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
         else wdma.load16(dst0 + i * nw * 1024, src, soff + wperm_inv4(i * nw * 8) * kstep);
       }
     }
+#endif
   };
   // ---- request cursors: hc = the plane stage being requested (two stages ahead of the MFMAs), wc = the last weight tap requested
   struct HCur { int item, slab, plane; bool valid; Geo q; } hc;
@@ -239,15 +257,19 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
       for (int dc = 0; dc < 2; ++dc) Bc[dc][kk] += dlt;
   };
   // fragments of one k-step into register set `buf`
+#ifdef S2_ABL_NOFRAG
+#define S2_FRAGS(buf, kk, DR, DC, P17) do { } while (0)
+#else
 #define S2_FRAGS(buf, kk, DR, DC, P17)                                                                      \
   do {                                                                                                      \
     A[buf][0] = ld16(s_w + Ac[kk]);                                                                         \
     _Pragma("unroll") for (int p = 0; p < TP; ++p) B[buf][p] = ld16(s_halo + Bc[DC][kk] + (p + (DR)) * ((P17) ? 17 * 128 : 16 * 128)); \
     _Pragma("unroll") for (int t = 1; t < TK; ++t) A[buf][t] = ld16(s_w + Ac[kk] + t * 2048);             \
   } while (0)
+#endif
 #define S2_MFMA(buf, SET)                                                                                   \
   do {                                                                                                      \
-    _Pragma("unroll") for (int t = 0; t < TK; ++t)                                                              \
+    _Pragma("unroll") for (int t = 0; t < (S2_ABL_MFMA_T); ++t)                                                          \
       _Pragma("unroll") for (int p = 0; p < TP; ++p)                                                        \
         acc[SET][t][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, A[buf][t]),   \
                                                                  __builtin_bit_cast(bf16x8_t, B[buf][p]), acc[SET][t][p], 0, 0, 0); \
@@ -422,7 +444,6 @@ bool conv_s2_ok(int dtype, const ConvArgs& a) {
   if (a.C % 64 != 0 || a.K % 128 != 0) return false;
   if ((size_t)a.H * a.W * a.C * 2 >= 0x7fffffffull) return false;
   if (a.bias && a.stats) return false;
-  if (a.relu && !a.bias) return false;          // the output clamp lives in the EVAL instance (chosen by the bias): conv_dma takes relu without one
   if (a.bias && 2 * a.K * sizeof(float) > 3584) return false;      // the biases of both accumulator sets sit in what LDS is left
   if (a.seg_images > 0 && a.N % a.seg_images != 0) return false;
   // the statistics rows are asked for without a dtype (sslcr_conv2d_partial_rows) and the fp32 mode runs these shapes on the gather
@@ -437,7 +458,6 @@ bool conv_s2_pair_ok(int dtype, const ConvArgs& a, const ConvArgs& d) {
   if (d.in_scale || d.residual || d.accumulate || d.mask_x || d.osh != 1) return false;
   if (d.x != a.x || d.N != a.N || d.H != a.H || d.W != a.W || d.C != a.C || d.K != a.K || d.PH != a.PH || d.PW != a.PW) return false;
   if ((a.bias != nullptr) != (d.bias != nullptr) || (a.stats != nullptr) != (d.stats != nullptr)) return false;
-  if (d.relu && !d.bias) return false;
   return true;
 }
 int conv_s2_rows(const ConvArgs& a) { return a.N * (a.PH / 16) * (a.PW / 16) * 4; }

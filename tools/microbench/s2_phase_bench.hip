@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
-#include "../../ssl_cr_histo_amd/csrc/conv_s2.hip"
+#include "conv_s2_abl.hip"
 namespace sslcr {
 int device_cus() { return 256; }
 }
