@@ -81,8 +81,118 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
   }
 }
 
+// LDS-staged form for the shapes that matter (M, N multiples of 32, K of 64; round 6).  What bounded the form above at 22 us for
+// fc.0 (0.67 GFLOP: 30 TF/s on a 157 TF/s pipe) is the operand FETCH, not its volume: a lane loads its own row's 16 bytes, so one
+// load instruction touches 64 separate 16-byte segments of 16 rows and the CU's address coalescer serialises them (2x2 tiles per wave,
+// operand prefetch and both together changed nothing -- 22-25 us each: tools/heads_bench.py, profiles/r06_heads_gemm.txt).  Here a workgroup owns a
+// 32 x 32 block of C and walks K in chunks of 64: the two 32 x 64 operand tiles are fetched with whole 256-byte rows per 16 lanes
+// (k-contiguous operands, AKC / BKC) or 128-byte rows per 8 lanes (k-strided ones, transposed on their way into LDS), double-buffered
+// through LDS with one barrier per chunk, and wave (wm, wn) runs the 16 x 16 tile's MFMAs from 16-byte fragment reads (row pitch 68
+// floats: the 16 rows of a fragment read hit 64 different banks).  Each output element sums its K in rising chunk order.
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void gemm_f32_lds_kernel(const float* __restrict__ A, long sa, const float* __restrict__ B, long sb,
+                                                           float* __restrict__ C, int M, int N, int K,
+                                                           const float* __restrict__ bias, int relu, int accumulate) {
+  constexpr int PITCH = 68;                                    // floats per LDS row (64 k + 4)
+  __shared__ __attribute__((aligned(16))) float lds[2][2][32 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = N / 32;
+  const int bm = blockIdx.x / tiles_n, bn = blockIdx.x - bm * tiles_n;
+  // sa / sb: the stride of the operand's NON-contiguous index (k-contiguous: elements per row i / j; k-strided: elements per k)
+  const float* Ab = AKC ? A + (long)(bm * 32) * sa : A + bm * 32;
+  const float* Bb = BKC ? B + (long)(bn * 32) * sb : B + bn * 32;
+  // operand registers of TWO chunks: chunk ch + 2 is requested at the top of chunk ch and staged at the end of chunk ch + 1 (with one
+  // chunk of lead the ~600 cycles of a chunk's MFMAs covered a third of the fetch: 15.5 us for fc.0 against a 3.4 us MFMA floor)
+  f32x4_t ra[2][2], rb[2][2];
+  auto fetch = [&](int kb, f32x4_t (&xa)[2], f32x4_t (&xb)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int c = tid + 256 * p;
+      if (AKC) xa[p] = *reinterpret_cast<const f32x4_t*>(Ab + (long)(c >> 4) * sa + kb + 4 * (c & 15));
+      else xa[p] = *reinterpret_cast<const f32x4_t*>(Ab + (long)(kb + (c >> 3)) * sa + 4 * (c & 7));
+      if (BKC) xb[p] = *reinterpret_cast<const f32x4_t*>(Bb + (long)(c >> 4) * sb + kb + 4 * (c & 15));
+      else xb[p] = *reinterpret_cast<const f32x4_t*>(Bb + (long)(kb + (c >> 3)) * sb + 4 * (c & 7));
+    }
+  };
+  auto stage = [&](int buf, const f32x4_t (&xa)[2], const f32x4_t (&xb)[2]) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int c = tid + 256 * p;
+      if (AKC) *reinterpret_cast<f32x4_t*>(&lds[buf][0][(c >> 4) * PITCH + 4 * (c & 15)]) = xa[p];
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[buf][0][(4 * (c & 7) + e) * PITCH + (c >> 3)] = xa[p][e];
+      }
+      if (BKC) *reinterpret_cast<f32x4_t*>(&lds[buf][1][(c >> 4) * PITCH + 4 * (c & 15)]) = xb[p];
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[buf][1][(4 * (c & 7) + e) * PITCH + (c >> 3)] = xb[p][e];
+      }
+    }
+  };
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  auto compute = [&](int buf) {
+    const float* la = &lds[buf][0][(wm * 16 + li) * PITCH + 4 * g];
+    const float* lb = &lds[buf][1][(wn * 16 + li) * PITCH + 4 * g];
+    f32x4_t fa[4], fb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      fa[u] = *reinterpret_cast<const f32x4_t*>(la + 16 * u);
+      fb[u] = *reinterpret_cast<const f32x4_t*>(lb + 16 * u);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][e], fb[u][e], acc, 0, 0, 0);
+  };
+  const int nchunks = K / 64;
+  fetch(0, ra[0], rb[0]);
+  if (nchunks > 1) fetch(64, ra[1], rb[1]);
+  stage(0, ra[0], rb[0]);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ch += 2) {
+    // even chunk: LDS buffer 0, registers set 0 is free (staged), set 1 holds chunk ch + 1
+    if (ch + 2 < nchunks) fetch((ch + 2) * 64, ra[0], rb[0]);
+    compute(0);
+    if (ch + 1 < nchunks) stage(1, ra[1], rb[1]);
+    __syncthreads();
+    if (ch + 1 >= nchunks) break;
+    if (ch + 3 < nchunks) fetch((ch + 3) * 64, ra[1], rb[1]);
+    compute(1);
+    if (ch + 2 < nchunks) stage(0, ra[0], rb[0]);
+    __syncthreads();
+  }
+  // D[row = 4g + q][col = li]
+  const int j = bn * 32 + wn * 16 + li;
+  const float bj = bias ? bias[j] : 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = bm * 32 + wm * 16 + 4 * g + q;
+    float v = acc[q] + bj;
+    float* cp = C + (long)row * N + j;
+    if (accumulate) v += *cp;
+    if (relu) v = fmaxf(v, 0.f);
+    *cp = v;
+  }
+}
+
 static hipError_t gemm(const float* A, long sa_i, long sa_k, const float* B, long sb_k, long sb_j, float* C, int M, int N, int K,
                        const float* bias, int relu, int accumulate, hipStream_t st) {
+  static const bool lds_on = [] { const char* e = getenv("SSLCR_GEMM_LDS"); return !e || atoi(e) != 0; }();     // 0: the direct-fetch form for everything (A/B runs)
+  const bool akc = sa_k == 1, bkc = sb_k == 1;
+  const long sa = akc ? sa_i : sa_k, sb = bkc ? sb_j : sb_k;
+  const bool lds_ok = lds_on && M % 32 == 0 && N % 32 == 0 && K % 64 == 0 && (akc || sa_i == 1) && (bkc || sb_j == 1) && (sa & 3) == 0 &&
+                      (sb & 3) == 0 && ((size_t)A & 15) == 0 && ((size_t)B & 15) == 0;
+  if (lds_ok) {
+    const dim3 grid((M / 32) * (N / 32));
+    if (akc && bkc) hipLaunchKernelGGL((gemm_f32_lds_kernel<true, true>), grid, dim3(256), 0, st, A, sa, B, sb, C, M, N, K, bias, relu, accumulate);
+    else if (akc) hipLaunchKernelGGL((gemm_f32_lds_kernel<true, false>), grid, dim3(256), 0, st, A, sa, B, sb, C, M, N, K, bias, relu, accumulate);
+    else if (bkc) hipLaunchKernelGGL((gemm_f32_lds_kernel<false, true>), grid, dim3(256), 0, st, A, sa, B, sb, C, M, N, K, bias, relu, accumulate);
+    else hipLaunchKernelGGL((gemm_f32_lds_kernel<false, false>), grid, dim3(256), 0, st, A, sa, B, sb, C, M, N, K, bias, relu, accumulate);
+    return hipGetLastError();
+  }
   const int tiles = cdiv(M, 16) * cdiv(N, 16);
   hipLaunchKernelGGL(gemm_f32_kernel, dim3(tiles), dim3(256), 0, st, A, sa_i, sa_k, B, sb_k, sb_j, C, M, N, K, bias, relu, accumulate);
   return hipGetLastError();

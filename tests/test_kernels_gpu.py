@@ -716,6 +716,31 @@ def test_relu_mask_as_bits_through_bn_act_and_bn_backward(nseg):
     assert float((a[2].float() != 0).float().mean()) > 0.2           # (the mask is not trivially empty)
 
 
+@pytest.mark.parametrize("shape", [(96, 1024, 512), (64, 512, 256), (160, 768, 128), (32, 64, 32)])
+def test_linear_lds_form(shape):
+    """the LDS-staged fp32 GEMM (gemm_f32_lds_kernel: M, N multiples of 32, K of 64 -- the fc.0 / fc.2 / FinetuneResNet shapes of a
+    step) in its four operand forms: forward (both k-contiguous), dx (B k-strided), dw (both k-strided, accumulating into a
+    non-zero buffer), with bias + ReLU and the ReLU mask"""
+    K = _k()
+    M, Kd, Nn = shape
+    x, w, b = rnd(161, (M, Kd)), rnd(162, (Nn, Kd), 0.03), rnd(163, (Nn,))
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.relu(F.linear(xr, wr, br))
+    y = K.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), relu=True)
+    close(y, yr, 2e-5, "linear fwd")
+    y0 = K.linear_fwd(x.to(DEV), w.to(DEV), None, relu=False)
+    close(y0, F.linear(x, w), 2e-5, "linear fwd, no bias")
+    dy = rnd(164, (M, Nn))
+    yr.backward(dy)
+    base = rnd(165, (Nn, Kd))
+    dw = base.clone().to(DEV)
+    db = torch.zeros(Nn, device=DEV)
+    dx = K.linear_bwd(x.to(DEV), w.to(DEV), dy.to(DEV), yact=y, dw=dw, db=db)
+    close(dx, xr.grad, 5e-5, "linear dx")
+    close(dw.cpu() - base, wr.grad, 5e-5, "linear dw")
+    close(db, br.grad, 5e-5, "linear db")
+
+
 def test_linear_and_loss():
     K = _k()
     M, Kd, Nn = 37, 1024, 512
