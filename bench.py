@@ -327,7 +327,9 @@ def also_child(args):
     torch.cuda.set_device(device)
     from ssl_cr_histo_amd import engine as E
     eng = E.set_engine(E.Engine(device, "bf16"))
-    also = {}
+    eng.set_aux_stream(bool(args.aux_stream))          # the side streams as in the headline run
+    eng.set_wgrad_stream(bool(args.wgrad_stream))
+    also = {"side_streams": {"aux_stream": bool(args.aux_stream), "wgrad_stream": bool(args.wgrad_stream)}}
 
     def barrier():
         torch.cuda.synchronize()
@@ -344,6 +346,8 @@ def also_child(args):
     rec("rsp_config3", "rsp", eng, 20, 5)
     rec("frozen_backbone_modules_student_60", "ssl_cr", eng, 20, 5, modules_student=60)
     eng32 = E.Engine(device, "fp32")
+    eng32.set_aux_stream(bool(args.aux_stream))
+    eng32.set_wgrad_stream(bool(args.wgrad_stream))
     rec("parity_mode_fp32", "ssl_cr", eng32, 4, 2)
     also["parity_mode_fp32"]["note"] = ("exact-parity engine mode (v_mfma_f32_16x16x4_f32, fp32 storage): the mode that holds the "
                                         "north-star 1e-3 against the reference goldens; peak = 157.3 TF fp32 matrix")
@@ -357,6 +361,8 @@ def also_child(args):
 
     def rec5(tag, dtype):
         e5 = eng if dtype == "bf16" else E.Engine(device, dtype)
+        e5.set_aux_stream(bool(args.aux_stream))
+        e5.set_wgrad_stream(bool(args.wgrad_stream))
         s, p, fl, c, k = make_workload("cam_cr", e5, a5, device, 0, 1)
         n5 = 8
         t = timed(s, 3, n5, barrier)
@@ -387,7 +393,7 @@ def also_records(args):
     python bench.py` the summary then covers exactly the headline workload (the legs launch the SAME kernels at other batch sizes;
     in one process their launches would be averaged into the headline's per-kernel durations)."""
     cmd = [sys.executable, os.path.abspath(__file__), "--also-child", "--batch_size", str(args.batch_size), "--mu", str(args.mu),
-           "--image_size", str(args.image_size)]
+           "--image_size", str(args.image_size), "--aux-stream", str(args.aux_stream), "--wgrad-stream", str(args.wgrad_stream)]
     env = _clean_profiler_env()
     try:
         proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=600)
@@ -429,7 +435,8 @@ def pmc_in_run(args):
     out = tempfile.mkdtemp(prefix="sslcr_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "2", "--no-roofline", "--no-cpu-baseline", "--no-also",
              "--no-pmc", "--workload", args.workload, "--batch_size", str(args.batch_size), "--mu", str(args.mu), "--image_size",
-             str(args.image_size), "--modules_student", str(args.modules_student), "--dtype", args.dtype]
+             str(args.image_size), "--modules_student", str(args.modules_student), "--dtype", args.dtype,
+             "--aux-stream", "0", "--wgrad-stream", "0"]        # per-kernel counters: one kernel at a time
     env = _clean_profiler_env()
     env["TMPDIR"] = "/tmp"
     t0 = time.time()

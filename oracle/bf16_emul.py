@@ -124,3 +124,43 @@ def teacher_logits(p, b, u_w, emulate, chunk=64):
             f = M.fc_head(p, torch.cat((e, e), 1))
             out.append(M.classifier_forward(p, torch.cat((f, f, f), 1)))
         return torch.cat(out)
+
+
+# ---------------------------------------------------------------- whole epochs under bf16 storage (round 6)
+def backbone_forward_emulated(p, b, x, train, pre="model.", taps=None):
+    """drop-in for oracle.model.backbone_forward with the engine's bf16 STORAGE points rounded: train mode like backbone_train
+    (and BatchNorm's running statistics updated from the rounded tensors, as oracle.model._bn does), eval mode like backbone_eval
+    (BatchNorm folded into bf16 filters)."""
+    if not train:
+        return backbone_eval(p, b, x, rnd, pre)
+    q = rnd
+    w = (lambda k: q(p[pre + k]))
+    x = q(F.conv2d(x, w("conv1.weight"), None, 2, 3))
+    x = q(F.max_pool2d(F.relu(M._bn(x, p, b, pre + "bn1", True)), 3, 2, 1))
+    for name, cin, cout, stride, ds in M.BLOCKS:
+        n = pre + name
+        o = q(F.conv2d(x, w(name + ".conv1.weight"), None, stride, 1))
+        o = q(F.relu(M._bn(o, p, b, n + ".bn1", True)))
+        o = q(F.conv2d(o, w(name + ".conv2.weight"), None, 1, 1))
+        o = M._bn(o, p, b, n + ".bn2", True)
+        if ds:
+            i = q(F.conv2d(x, w(name + ".downsample.0.weight"), None, stride, 0))
+            i = M._bn(i, p, b, n + ".downsample.1", True)
+        else:
+            i = x
+        x = q(F.relu(o + i))
+    return torch.flatten(F.adaptive_avg_pool2d(x, 1), 1)
+
+
+class emulating:
+    """`with emulating():` -- every oracle.model forward inside (steps / epochs: train(), validate()) stores what the engine's bf16
+    mode stores in bf16.  A yardstick for tolerances (tests/golden/make_bf16_yard_small.py), never a parity claim."""
+
+    def __enter__(self):
+        self._saved = M.backbone_forward
+        M.backbone_forward = backbone_forward_emulated
+        return self
+
+    def __exit__(self, *exc):
+        M.backbone_forward = self._saved
+        return False
