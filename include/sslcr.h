@@ -68,6 +68,13 @@ typedef struct sslcr_conv_desc {
      segment's BatchNorm is mask_scale / mask_shift / mask_mean + s * seg_stride.  bf16 only; sslcr_conv2d fails where the kernel
      serving the shape has no segment form (sslcr_conv2d_segments_ok). */
   int seg_images, seg_stride;
+  /* library version >= 6.  [K] or NULL: y = epilogue(acc * out_scale[k] + bias[k] ...) -- eval-mode BatchNorm with its scale kept OUT
+     of the filters: w is then the plain (bf16-rounded) filter, bias the BatchNorm shift (sslcr_pack_desc.scale_out).  The bf16 engine
+     runs the teacher / validate() forward this way: round(w) followed by the fp32 scale leaves 3.6 x less SYSTEMATIC error in the
+     logits than round(w * scale), and the consistency loss -- an average over the unlabeled batch -- keeps exactly that part
+     (full-size iteration: 1.75e-3 -> 4.9e-4, tools/bf16_teacher_fold_experiment.py, profiles/r06_bf16_teacher_fold_experiment.txt).
+     Only with bias (the eval forms); not with stats / mask_x. */
+  const float* out_scale;
 } sslcr_conv_desc;
 int sslcr_conv2d(int dtype, const sslcr_conv_desc* d, void* stream);
 int sslcr_conv2d_partial_rows(const sslcr_conv_desc* d);
@@ -144,6 +151,7 @@ typedef struct sslcr_stem_desc {
   const void* x2;         /* optional second input segment: images n >= n_split are read from x2[n - n_split] -- the
                              reference's torch.cat((inputs_x, inputs_u_s)) (eval_BreastPathQ_SSL_CR.py:82) without the copy */
   int n_split;
+  const float* out_scale; /* [64] or NULL, as sslcr_conv_desc.out_scale (library version >= 6) */
 } sslcr_stem_desc;
 int sslcr_stem_conv(int dtype, const sslcr_stem_desc* d, void* stream);
 int sslcr_stem_partial_rows(const sslcr_stem_desc* d);
@@ -297,6 +305,8 @@ typedef struct sslcr_pack_desc {
   const float* gamma; const float* beta; const float* rmean; const float* rvar; float eps; float* bias_out;
   int K, C, R, S;
   int dgrad_flip;         /* w_dgrad taps reversed ([C][R-1-r][S-1-s][K]): a stride-1 dgrad then IS a plain conv of dY */
+  float* scale_out;       /* library version >= 6, with gamma: [K] <- gamma / sqrt(rvar + eps) and w_fwd keeps the PLAIN filter (the fold's
+                             scale goes to the conv's epilogue: sslcr_conv_desc.out_scale); bias_out is the shift either way.  NULL: folded */
 } sslcr_pack_desc;
 int sslcr_pack_conv(int dtype, const sslcr_pack_desc* d, void* stream);
 int sslcr_pack_stem(int dtype, const sslcr_pack_desc* d, void* stream);

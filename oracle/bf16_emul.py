@@ -96,14 +96,17 @@ def sup_grads(kind, p, x, y, emulate):
     return {k: v.grad.clone() for k, v in p.items()}, logits.detach(), float(loss.detach())
 
 
-def backbone_eval(p, b, x, q=rnd, pre="model."):
-    """eval-mode resnet18 backbone the way the engine's bf16 mode runs the TEACHER: BatchNorm's running statistics folded
-    into the filters (w * gamma / sqrt(var + eps), rounded to bf16 AFTER the fold; the shift stays fp32 as the conv's
-    bias), every conv output stored in bf16 after its bias / residual / ReLU epilogue (q = identity gives fp32)."""
+def backbone_eval(p, b, x, q=rnd, pre="model.", fold=False):
+    """eval-mode resnet18 backbone the way the engine's bf16 mode runs the TEACHER (and validate()): every conv output stored in bf16
+    after its scale / bias / residual / ReLU epilogue (q = identity gives fp32).  Round 6: the filters are the PLAIN weights rounded
+    to bf16 and BatchNorm's scale gamma / sqrt(var + eps) is applied in fp32 in the epilogue (sslcr_conv_desc.out_scale).  fold=True is the engine of rounds 1-5: the scale folded into the
+    filters BEFORE the rounding (tools/bf16_teacher_fold_experiment.py compares the two)."""
     def conv(x, cname, bname, stride, pad):
         s = p[pre + bname + ".weight"] / torch.sqrt(b[pre + bname + ".running_var"] + 1e-5)
         sh = p[pre + bname + ".bias"] - b[pre + bname + ".running_mean"] * s
-        return F.conv2d(x, q(p[pre + cname + ".weight"] * s.view(-1, 1, 1, 1)), sh, stride, pad)
+        if fold:
+            return F.conv2d(x, q(p[pre + cname + ".weight"] * s.view(-1, 1, 1, 1)), sh, stride, pad)
+        return F.conv2d(x, q(p[pre + cname + ".weight"]), None, stride, pad) * s.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
     x = q(x)
     x = F.max_pool2d(q(F.relu(conv(x, "conv1", "bn1", 2, 3))), 3, 2, 1)
     for name, cin, cout, stride, ds in M.BLOCKS:
@@ -130,7 +133,7 @@ def teacher_logits(p, b, u_w, emulate, chunk=64):
 def backbone_forward_emulated(p, b, x, train, pre="model.", taps=None):
     """drop-in for oracle.model.backbone_forward with the engine's bf16 STORAGE points rounded: train mode like backbone_train
     (and BatchNorm's running statistics updated from the rounded tensors, as oracle.model._bn does), eval mode like backbone_eval
-    (BatchNorm folded into bf16 filters)."""
+    (plain bf16 filters, BatchNorm's scale and shift in the fp32 epilogue)."""
     if not train:
         return backbone_eval(p, b, x, rnd, pre)
     q = rnd

@@ -19,7 +19,7 @@ def krsc(w_kcrs):
 
 
 def conv_fwd(x_nhwc, w_krsc, stride, pad, in_scale=None, in_shift=None, in_relu=False,
-             bias=None, residual=None, relu=False):
+             bias=None, residual=None, relu=False, out_scale=None):
     """y = epilogue(conv(prologue(x))).  prologue: per-channel x*scale+shift (+relu) applied to
     in-bounds pixels only (zero padding stays zero) == BN-apply fused into the consumer's load."""
     x = x_nhwc.float()
@@ -29,6 +29,8 @@ def conv_fwd(x_nhwc, w_krsc, stride, pad, in_scale=None, in_shift=None, in_relu=
             x = F.relu(x)
     y = F.conv2d(nchw(x), w_krsc.float().permute(0, 3, 1, 2), None, stride, pad)
     y = nhwc(y)
+    if out_scale is not None:            # eval-mode BatchNorm scale kept out of the filters (sslcr_conv_desc.out_scale)
+        y = y * out_scale
     if bias is not None:
         y = y + bias
     if residual is not None:

@@ -27,11 +27,11 @@ ConvDesc = _S("ConvDesc", [("x", vp), ("w", vp), ("y", vp), ("in_scale", vp), ("
               [(k, i32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "PH", "PW", "OH", "OW", "osh",
                                   "transposed", "in_relu", "relu", "accumulate", "pix_mul", "pix_off_h", "pix_off_w")] +
               [("tap_mask", C.c_uint), ("mask_x", vp), ("mask_scale", vp), ("mask_shift", vp), ("mask_mean", vp),
-               ("par4", i32), ("seg_images", i32), ("seg_stride", i32)])
+               ("par4", i32), ("seg_images", i32), ("seg_stride", i32), ("out_scale", vp)])
 WgradDesc = _S("WgradDesc", [("x", vp), ("dy", vp), ("dw", vp), ("in_scale", vp), ("in_shift", vp), ("in_relu", i32)] +
                [(k, i32) for k in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "OH", "OW", "seg_images", "seg_stride")])
 StemDesc = _S("StemDesc", [("x", vp), ("w", vp), ("y", vp), ("bias", vp), ("stats", vp)] +
-              [(k, i32) for k in ("N", "H", "W", "OH", "OW", "in_f32", "relu")] + [("x2", vp), ("n_split", i32)])
+              [(k, i32) for k in ("N", "H", "W", "OH", "OW", "in_f32", "relu")] + [("x2", vp), ("n_split", i32), ("out_scale", vp)])
 StemWgradDesc = _S("StemWgradDesc", [("x", vp), ("dy", vp), ("dw", vp)] +
                    [(k, i32) for k in ("N", "H", "W", "OH", "OW", "in_f32")] + [("x2", vp), ("n_split", i32)])
 BnFinalizeDesc = _S("BnFinalizeDesc", [("partials", vp), ("rows", i32), ("C", i32), ("count", f64), ("gamma", vp),
@@ -64,7 +64,7 @@ ColourAugDesc = _S("ColourAugDesc", [("src", vp), ("dst", vp), ("shift", vp), ("
 BrightnessContrastDesc = _S("BrightnessContrastDesc", [("src", vp), ("dst", vp), ("alpha_beta", vp), ("apply", vp), ("stats", vp),
                                                        ("N", i32), ("H", i32), ("W", i32)])
 PackDesc = _S("PackDesc", [("w", vp), ("w_fwd", vp), ("w_dgrad", vp), ("gamma", vp), ("beta", vp), ("rmean", vp),
-                           ("rvar", vp), ("eps", f32), ("bias_out", vp)] + [(k, i32) for k in ("K", "C", "R", "S", "dgrad_flip")])
+                           ("rvar", vp), ("eps", f32), ("bias_out", vp)] + [(k, i32) for k in ("K", "C", "R", "S", "dgrad_flip")] + [("scale_out", vp)])
 
 Fp8Desc = _S("Fp8Desc", [("w8", vp), ("w_dequant", vp), ("x_scale", f32), ("x_scale_dev", vp), ("amax_out", vp)])
 PackFp8Desc = _S("PackFp8Desc", [("w", vp), ("w8", vp), ("w_dequant", vp), ("gamma", vp), ("beta", vp), ("rmean", vp), ("rvar", vp),

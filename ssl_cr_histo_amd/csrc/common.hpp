@@ -273,6 +273,21 @@ __device__ __forceinline__ void conv_store_tile_t(const f32x4_t (&acc)[TK][TP], 
     }
   }
 }
+// sslcr_conv_desc.out_scale (eval-mode BatchNorm scale kept out of the filters): acc <- acc * out_scale[kb + 4 t + j], in place, in front
+// of the bias epilogue.  osc_kb = out_scale + kb (16-byte aligned: kb is a multiple of 4 TK); a uniform branch at the call sites, so the
+// forms without it (train forward, every dgrad) pay nothing.
+template <int TK, int TP>
+__device__ __forceinline__ void conv_scale_acc(f32x4_t (&acc)[TK][TP], const float* osc_kb) {
+#pragma unroll
+  for (int t = 0; t < TK; ++t) {
+    const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(osc_kb + 4 * t);
+#pragma unroll
+    for (int p = 0; p < TP; ++p)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t][p][j] *= s4[j];
+  }
+}
+
 template <typename T, int TK, int TP>
 __device__ __forceinline__ void conv_store_tile(const f32x4_t (&acc)[TK][TP], const float (&bias)[4 * TK], const size_t (&off)[TP],
                                                 const bool (&ok)[TP], char* yg, const char* rg, bool accumulate, bool relu) {

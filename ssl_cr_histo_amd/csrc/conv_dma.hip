@@ -203,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(const ConvArgs a) {
 
   // ---------------- epilogue: lane (li = pixel within 16-tile, g) holds kouts kb .. kb+15 of its pixels
   const int kb = k0 + wk * 64 + g * (4 * TK);
+  if (a.out_scale) conv_scale_acc<TK, TP>(acc, a.out_scale + kb);
   float bias[4 * TK];
   if (a.bias) {
 #pragma unroll

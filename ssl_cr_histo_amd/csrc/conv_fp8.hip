@@ -355,7 +355,7 @@ __global__ __launch_bounds__(512) void conv3x3_fp8_kernel(const ConvArgs a, cons
 
 // 0: not served; 16: 16x16 tiles; 8: four images x 8x8
 int conv_fp8_mode(const ConvArgs& a) {
-  if (a.pix_mul > 1 || a.tap_mask || a.mask_x || a.par4) return 0;
+  if (a.pix_mul > 1 || a.tap_mask || a.mask_x || a.par4 || a.out_scale) return 0;      // (its per-kout scale is w_dequant)
   if (a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1 || a.transposed || a.accumulate || a.osh != 1) return 0;
   if (a.PH != a.H || a.PW != a.W || a.OH != a.H || a.OW != a.W) return 0;
   if (a.C % 128 != 0 || a.K % 128 != 0 || a.C > 512) return 0;

@@ -135,10 +135,14 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
   const bool mk = !XF && !RAW && a.mask_x != nullptr;
   float* s_msh = s_bias + a.K;
   float* s_mmu = s_msh + a.K;
+  // eval-mode BatchNorm scale kept out of the filters (sslcr_conv_desc.out_scale; never together with the mask): the array behind s_bias
+  const bool osc_on = !XF && !RAW && !mk && a.out_scale != nullptr;
+  float* s_osc = s_msh;
   for (int i = tid; i < a.K; i += NT) {
     const size_t mo = (size_t)seg * a.seg_stride + i;          // the mask's BatchNorm is the segment's own
     s_bias[i] = mk ? a.mask_scale[mo] : (a.bias ? a.bias[i] : 0.f);
     if (mk) { s_msh[i] = a.mask_shift[mo]; s_mmu[i] = a.mask_mean[mo]; }
+    if (osc_on) s_osc[i] = a.out_scale[i];
   }
   const float relu_lo = a.in_relu ? 0.f : -__builtin_inff();
   const float out_lo = a.relu ? 0.f : -__builtin_inff();
@@ -498,6 +502,7 @@ __global__ __launch_bounds__(256 * WK, WK == 1 ? 1 : 2) void conv3x3_h16_kernel(
           }
         }
       } else {
+      if (osc_on) conv_scale_acc<TK, TP>(acc, s_osc + kb);        // (uniform; LDS reads)
       float bias[4 * TK];
 #pragma unroll
       for (int j = 0; j < 4 * TK; ++j) bias[j] = s_bias[kb + j];
@@ -644,8 +649,17 @@ bool conv_h16_ok(int dtype, const ConvArgs& a) {
   if (a.in_scale && a.residual) return false;          // not a ResNet combination; the older halo kernels take it
   if (a.mask_x) {
     // (a.stats is checked at launch: sslcr_conv2d_partial_rows asks before the rows buffer exists)
-    if (!a.mask_scale || !a.mask_shift || !a.mask_mean || a.in_scale || a.bias || a.residual || a.relu) return false;
+    if (!a.mask_scale || !a.mask_shift || !a.mask_mean || a.in_scale || a.bias || a.residual || a.relu || a.out_scale) return false;
     if (18 * 24 * 128 + 2 * 3 * (a.K % 128 == 0 ? 128 : 64) * 128 + 2 * a.C * 4 + 8 * 128 * 4 + 3 * a.K * 4 > 160 * 1024) return false;
+  }
+  if (a.out_scale) {
+    // one more K-float array in LDS (the input-transform and train-forward instances have no output scale: bias forms only)
+    if (a.in_scale || a.stats || !a.bias) return false;
+    const int mode = h16_mode(dtype, a);
+    if (mode == 0) return false;
+    const int bko = a.K % 128 == 0 ? 128 : 64;
+    if (!(a.C == 64 && a.K == 64) &&
+        (mode == 16 ? 18 * 24 : 4 * 10 * 10) * 128 + 2 * 3 * bko * 128 + 2 * a.C * 4 + 8 * bko * 4 + 2 * a.K * 4 > 160 * 1024) return false;
   }
   return h16_mode(dtype, a) != 0;
 }
@@ -698,7 +712,7 @@ static bool h16_raw(const ConvArgs& a) {
 template <typename T, int BKO, int WK, bool XF, bool WR = false, bool RAW = false, int TW = 16>
 static hipError_t launch_h(const ConvArgs& a, hipStream_t st, int row0 = 0) {
   const size_t lds = (TW == 16 ? 18 * 24 : 4 * 10 * 10) * 128 + (WR ? 3 : 2) * 3 * BKO * 128 + 2 * a.C * sizeof(float) + 8 * BKO * sizeof(float) +
-                     (a.mask_x ? 3 : 1) * a.K * sizeof(float);
+                     (a.mask_x ? 3 : (a.out_scale ? 2 : 1)) * a.K * sizeof(float);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   auto kern = conv3x3_h16_kernel<T, BKO, WK, XF, WR, RAW, TW>;
   static std::atomic<bool> attr_done{false};

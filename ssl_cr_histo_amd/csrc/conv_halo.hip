@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_kernel(const ConvArgs a) 
 
   // ---------------- epilogue (same conventions as conv_igemm_kernel)
   const int kb = k0 + wk * (BKO / 2) + g * (4 * TK);
+  if (a.out_scale) conv_scale_acc<TK, TP>(acc, a.out_scale + kb);
   float bias[4 * TK];
 #pragma unroll
   for (int j = 0; j < 4 * TK; ++j) bias[j] = a.bias ? a.bias[kb + j] : 0.f;

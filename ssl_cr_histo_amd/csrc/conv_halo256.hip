@@ -265,6 +265,7 @@ __global__ __launch_bounds__(256 * WK, 2) void conv3x3_halo256_kernel(const Conv
 
   // ---------------- epilogue
   const int kb = k0 + wk * (BKO / WK) + g * (4 * TK);
+  if (a.out_scale) conv_scale_acc<TK, TP>(acc, a.out_scale + kb);
   float bias[4 * TK];
   if (a.bias) {
 #pragma unroll

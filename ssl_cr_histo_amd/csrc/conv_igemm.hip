@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
   // ---------------- epilogue: lane (li = pixel within 16-tile, g) holds kouts kb .. kb+4*TK-1 of its pixels
   const int kb = k0 + wk * (BKO / 2) + g * (4 * TK);
+  if (a.out_scale) conv_scale_acc<TK, TP>(acc, a.out_scale + kb);
   float bias[4 * TK];
 #pragma unroll
   for (int j = 0; j < 4 * TK; ++j) bias[j] = a.bias ? a.bias[kb + j] : 0.f;
@@ -361,6 +362,7 @@ bool conv_segments_ok(int dtype, const ConvArgs& a) {
 
 hipError_t launch_conv(int dtype, const ConvArgs& a, hipStream_t st) {
   if (!conv_segments_ok(dtype, a)) return hipErrorInvalidValue;
+  if (a.out_scale && (!a.bias || a.stats || a.mask_x)) return hipErrorInvalidValue;      // the output scale exists in the bias (eval) epilogues only
   if (conv_h16_ok(dtype, a)) return launch_conv_h16(dtype, a, st);
   if (a.mask_x) return hipErrorInvalidValue;        // the BatchNorm-backward front end exists in the 16x16-tile kernel only
   const int q = conv_halo256_mode(dtype, a);

@@ -118,7 +118,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
     const size_t mo = (size_t)seg * a.seg_stride + tid;        // the mask's BatchNorm is the segment's own
     s_bias[tid] = mk ? a.mask_scale[mo] : (a.bias ? a.bias[tid] : 0.f);
     if (mk) { s_msh[tid] = a.mask_shift[mo]; s_mmu[tid] = a.mask_mean[mo]; }
+    else if (a.out_scale) s_msh[tid] = a.out_scale[tid];       // sslcr_conv_desc.out_scale (eval forms: never with the mask) in the mask's array
   }
+  const bool osc_on = !mk && !XF && a.out_scale != nullptr;
   for (int i = tid; i < 1024; i += 512) s_f[320 + i] = 0.f;
 
   // ---- per-thread halo staging roles (group-local), fixed for the whole walk
@@ -343,6 +345,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pp64_kernel(const ConvArgs a, 
                 st16(yg + out_off(cur, p) + q * 64, PackH<T>::run(vq));
               }
           } else {
+            if (osc_on) {                          // eval-mode BatchNorm scale kept out of the filters: acc * scale in place (uniform)
+#pragma unroll
+              for (int j = 0; j < 4 * TK; ++j) {
+                const float sj = s_msh[kb + (j >> 3) * 32 + (j & 7)];
+#pragma unroll
+                for (int p = 0; p < TP; ++p) acc[j >> 2][p][j & 3] *= sj;
+              }
+            }
             float bias[4 * TK];
 #pragma unroll
             for (int j = 0; j < 4 * TK; ++j) bias[j] = s_bias[kb + (j >> 3) * 32 + (j & 7)];
@@ -442,7 +452,8 @@ bool conv_pp64_ok(int dtype, const ConvArgs& a) {
   if ((size_t)a.N * a.H * a.W * 64 * 2 >= ((size_t)1 << 32)) return false;       // the kernel addresses with 32-bit byte offsets
   if (a.W > 2048) return false;                                                  // halo roles pack a pixel offset of up to 17 W + 17 into 16 bits
   return on && dtype == DT_BF16 && a.C == 64 && a.K == 64 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && !a.transposed &&
-         a.H % 16 == 0 && a.W % 16 == 0 && !(a.in_scale && (a.residual || a.mask_x));
+         a.H % 16 == 0 && a.W % 16 == 0 && !(a.in_scale && (a.residual || a.mask_x)) &&
+         !(a.out_scale && (a.in_scale || a.mask_x || a.stats || !a.bias));
 }
 // rows of a.stats: what conv3x3_h16 would write for this shape (one 64-kout block; the caller sized the buffer before it knew the
 // dtype); with segments -- a bf16-only form -- exactly this grid's rows, so that segment s owns rows [s, s + 1) * rows / nseg

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* s_halo = smem;
   char* s_w = smem + NHB * HB;
-  float* s_bias = reinterpret_cast<float*>(s_w + NWS * WS);     // EVAL: [2][K] (conv1, projection)
+  // EVAL: [2 (bias, out_scale)][2 (conv1, projection)][128] of the kout block bk0 (reloaded in the output stage of an item whose block differs)
+  float* s_bias = reinterpret_cast<float*>(s_w + NWS * WS);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,12 +73,16 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
   const float out_lo = a.relu ? 0.f : -__builtin_inff();
   const float out_lo_d = (PAIR && d.relu) ? 0.f : -__builtin_inff();
 
-  if (EVAL) {
-    for (int i = tid; i < a.K; i += 512) {
-      s_bias[i] = a.bias ? a.bias[i] : 0.f;
-      if (PAIR) s_bias[a.K + i] = d.bias ? d.bias[i] : 0.f;
+  // bias (the folded BatchNorm's shift) and sslcr_conv_desc.out_scale (1 where the scale sits in the filters) of one 128-kout block
+  auto load_affine = [&](int k0) {
+    if (tid < 128) {
+      s_bias[tid] = a.bias ? a.bias[k0 + tid] : 0.f;
+      s_bias[128 + tid] = (PAIR && d.bias) ? d.bias[k0 + tid] : 0.f;
+      s_bias[256 + tid] = a.out_scale ? a.out_scale[k0 + tid] : 1.f;
+      s_bias[384 + tid] = (PAIR && d.out_scale) ? d.out_scale[k0 + tid] : 1.f;
     }
-  }
+  };
+  const bool osc_on = EVAL && (a.out_scale != nullptr || (PAIR && d.out_scale != nullptr));
 
   const bool kfast = kshift >= 0;
   struct Geo { int k0, tile, n0, oh0, ow0; };
@@ -212,6 +217,8 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
 
   // ---- pipeline fill: planes of stages 0 and 1 (OO, OE of the first item's slab 0), weight taps 0 and 1
   Geo cur = geom(first);
+  int bk0 = cur.k0;
+  if (EVAL) load_affine(bk0);                  // (in front of the DMA requests: the barrier below publishes it)
   hc.item = first; hc.slab = 0; hc.plane = 1; hc.valid = true; hc.q = cur;
   wc.item = first; wc.slab = 0; wc.tap = 1; wc.valid = true; wc.k0 = cur.k0;
   issue_w(cur.k0, 0, 0, 0, 8, wave, wsrc0, wsrc0d);
@@ -337,8 +344,16 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
     slab = 0;
     // ---------------- output stage of the finished item (the next item's first fragments are in flight)
     S2_T(te0);
+    if (EVAL && cur.k0 != bk0) {               // uniform; a kout-block-major walk crosses a block boundary a few times per launch
+      __syncthreads();                         // (drains this wave's DMA once: rare)
+      bk0 = cur.k0;
+      load_affine(bk0);
+      __syncthreads();
+      prev_ok = false;                         // the next barrier waits vmcnt(0): the counted waits assumed the requests above were the only ones
+    }
     {
       const int kb = cur.k0 + wk * 64 + g * 16;
+      const int kl = wk * 64 + g * 16;
 #pragma unroll
       for (int s = 0; s < (PAIR ? 2 : 1); ++s) {
         char* yo = s ? ydg : yg;
@@ -346,8 +361,16 @@ __global__ __launch_bounds__(512, 2) void conv_s2_kernel(const ConvArgs a, const
         const float lo = s ? out_lo_d : out_lo;
         float bias[16];
         if (EVAL) {
+          if (osc_on) {                        // eval-mode BatchNorm scale kept out of the filters: acc * scale in place
 #pragma unroll
-          for (int j = 0; j < 16; ++j) bias[j] = s_bias[s * a.K + kb + j];
+            for (int j = 0; j < 16; ++j) {
+              const float sj = s_bias[256 + s * 128 + kl + j];
+#pragma unroll
+              for (int p = 0; p < TP; ++p) acc[s][j >> 2][p][j & 3] *= sj;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) bias[j] = s_bias[s * 128 + kl + j];
         }
 #pragma unroll
         for (int p = 0; p < TP; ++p) {
@@ -423,7 +446,7 @@ bool conv_s2_ok(int dtype, const ConvArgs& a) {
   if ((size_t)a.H * a.W * a.C * 2 >= 0x7fffffffull) return false;
   if (a.bias && a.stats) return false;
   if (a.relu && !a.bias) return false;          // the output clamp lives in the EVAL instance (chosen by the bias): conv_dma takes relu without one
-  if (a.bias && 2 * a.K * sizeof(float) > 3584) return false;      // the biases of both accumulator sets sit in what LDS is left
+  if (a.out_scale && !a.bias) return false;
   if (a.seg_images > 0 && a.N % a.seg_images != 0) return false;
   // the statistics rows are asked for without a dtype (sslcr_conv2d_partial_rows) and the fp32 mode runs these shapes on the gather
   // kernel: served only where that kernel's row count is this one's (M / 64: its 128-pixel tiles, M >= 2048)
@@ -438,13 +461,14 @@ bool conv_s2_pair_ok(int dtype, const ConvArgs& a, const ConvArgs& d) {
   if (d.x != a.x || d.N != a.N || d.H != a.H || d.W != a.W || d.C != a.C || d.K != a.K || d.PH != a.PH || d.PW != a.PW) return false;
   if ((a.bias != nullptr) != (d.bias != nullptr) || (a.stats != nullptr) != (d.stats != nullptr)) return false;
   if (d.relu && !d.bias) return false;
+  if (d.out_scale && !d.bias) return false;
   return true;
 }
 int conv_s2_rows(const ConvArgs& a) { return a.N * (a.PH / 16) * (a.PW / 16) * 4; }
 
 template <bool PAIR, bool EVAL>
 static hipError_t launch_s2(const ConvArgs& a, const ConvArgs& d, hipStream_t st) {
-  const size_t lds = 3 * 289 * 128 + 3 * 128 * 128 + (EVAL ? 2 * a.K * sizeof(float) : 0);
+  const size_t lds = 3 * 289 * 128 + 3 * 128 * 128 + (EVAL ? 4 * 128 * sizeof(float) : 0);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   auto kern = conv_s2_kernel<PAIR, EVAL>;
   static std::atomic<bool> attr_done{false};

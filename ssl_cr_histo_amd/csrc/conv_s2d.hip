@@ -288,7 +288,7 @@ bool conv_s2d_ok(int dtype, const ConvArgs& a) {
   static const bool on = [] { const char* e = getenv("SSLCR_S2D"); return !e || atoi(e) != 0; }();    // 0: the gather kernel keeps the shape (A/B runs)
   if (!on || dtype != DT_BF16) return false;
   if (!a.par4 || !a.transposed || a.stride != 2 || a.R != 3 || a.S != 3 || a.pad != 1 || a.pix_mul != 2 || a.tap_mask) return false;
-  if (a.in_scale || a.residual || a.accumulate || a.mask_x || a.bias || a.relu || a.stats || a.osh != 1 || a.seg_images > 0) return false;
+  if (a.in_scale || a.residual || a.accumulate || a.mask_x || a.bias || a.out_scale || a.relu || a.stats || a.osh != 1 || a.seg_images > 0) return false;
   if (a.H % 16 != 0 || a.W % 16 != 0 || a.PH != a.H || a.PW != a.W || a.OH != 2 * a.H || a.OW != 2 * a.W) return false;
   if (a.C % 64 != 0 || a.K % 64 != 0) return false;
   if ((size_t)a.H * a.W * a.C * 2 >= 0x7fffffffull) return false;

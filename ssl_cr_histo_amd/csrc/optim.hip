@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const PackArgs a) {
     const float w = a.w[((size_t)k * a.C + c) * RS + rs];
     if (a.w_fwd) {
       float f = 1.f;
-      if (a.gamma) f = a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
+      if (a.gamma && !a.scale_out) f = a.gamma[k] / sqrtf(a.rvar[k] + a.eps);      // (scale_out: the scale goes to the conv's epilogue)
       Elem<T>::st(reinterpret_cast<T*>(a.w_fwd) + i, w * f);
     }
     if (a.w_dgrad) Elem<T>::st(reinterpret_cast<T*>(a.w_dgrad) + ((size_t)c * RS + (a.dgrad_flip ? RS - 1 - rs : rs)) * a.K + k, w);
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const PackArgs a) {
     for (int k = blockIdx.x * 256 + threadIdx.x; k < a.K; k += gridDim.x * 256) {
       const float f = a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
       a.bias_out[k] = a.beta[k] - a.rmean[k] * f;
+      if (a.scale_out) a.scale_out[k] = f;
     }
   }
 }
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void pack_stem_kernel(const PackArgs a) {
     float w = 0.f;
     if (c < 3 && s < 7) {
       w = a.w[((k * 3 + c) * 7 + r) * 7 + s];
-      if (a.gamma) w *= a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
+      if (a.gamma && !a.scale_out) w *= a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
     }
     Elem<T>::st(reinterpret_cast<T*>(a.w_fwd) + i, w);
   }
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256) void pack_stem_kernel(const PackArgs a) {
     const int k = threadIdx.x;
     const float f = a.gamma[k] / sqrtf(a.rvar[k] + a.eps);
     a.bias_out[k] = a.beta[k] - a.rmean[k] * f;
+    if (a.scale_out) a.scale_out[k] = f;
   }
 }
 hipError_t launch_pack_stem(int dtype, const PackArgs& a, hipStream_t st) {

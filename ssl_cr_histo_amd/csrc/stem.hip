@@ -247,6 +247,17 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
         }
       }
     }
+    // sslcr_stem_desc.out_scale (eval-mode BatchNorm scale kept out of the filters; bias forms only): acc * scale in place (uniform)
+    if (a.out_scale) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float sj = a.out_scale[STEM_CH(t, g, j)];
+          acc[t][0][j] *= sj;
+          acc[t][1][j] *= sj;
+        }
+    }
     // epilogue: lane holds kouts g*16 .. g*16+15 of pixel (ho0+2*wave+p, wo0+li)
     // (the kernel is VALU-bound -- 56 MFMAs against ~650 VALU per tile and wave -- so the common training case, a full tile
     // with no bias/ReLU, takes a path without the per-element selects, adds and the integer bf16 rounding)

@@ -117,9 +117,12 @@ __global__ __launch_bounds__(SP_NT) void stem_pool_fwd_kernel(const StemArgs a, 
     const u32x4_t z{0u, 0u, 0u, 0u};
     for (int i = tid; i < (2 * HALO_B + 2 * SP_PP + a.OW * 128) / 16; i += SP_NT) st16(smem + 64 * SP_WROW + i * 16, z);
   }
-  float bias[16];
+  float bias[16], osc[16];                   // osc: sslcr_stem_desc.out_scale (1 where the BatchNorm scale sits in the filters: x * 1 + b is x + b)
 #pragma unroll
-  for (int j = 0; j < 16; ++j) bias[j] = a.bias ? a.bias[SP_CH(j >> 2, g, j & 3)] : 0.f;
+  for (int j = 0; j < 16; ++j) {
+    bias[j] = a.bias ? a.bias[SP_CH(j >> 2, g, j & 3)] : 0.f;
+    osc[j] = a.out_scale ? a.out_scale[SP_CH(j >> 2, g, j & 3)] : 1.f;
+  }
   __syncthreads();
 
   // the walk: item = image * tiles_img + band * tcols + tile column, this workgroup's images blockIdx.x, + gridDim.x, ...
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(SP_NT) void stem_pool_fwd_kernel(const StemArgs a, 
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float o = acc[t][p][j] + bias[t * 4 + j];
+          const float o = fmaf(acc[t][p][j], osc[t * 4 + j], bias[t * 4 + j]);
           v[t * 4 + j] = a.relu ? relu0(o) : o;
         }
       const int prow = 1 + 2 * wave + p, pcol = 1 + li;

@@ -37,13 +37,14 @@ last_wgrad_kernel = ""       # ... and the most recent conv2d_wgrad()
 
 def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bias=None, residual=None, relu=False,
            want_stats=False, out=None, transposed=False, out_hw=None, osh=1, accumulate=False, pixel_hw=None,
-           pix_mul=0, pix_off=(0, 0), tap_mask=0, mask=None, par4=False, seg_images=0):
+           pix_mul=0, pix_off=(0, 0), tap_mask=0, mask=None, par4=False, seg_images=0, out_scale=None):
     """x NHWC [N,H,W,C], w KRSC [K,R,S,C] -> y NHWC (+ partial stats [rows,2,K] fp32).
 
+    out_scale [K] (with bias): y = epilogue(acc * out_scale + bias): eval-mode BatchNorm with its scale kept out of the filters.
     transposed=True is the dgrad gather: pixel space = the conv's input (pixel_hw), x = dY, w = [C][R][S][K].
     mask = (x_bn [like y], scale [K], shift [K], mean [K]): BatchNorm-backward front end, see sslcr_conv_desc.mask_x.
     seg_images > 0: N / seg_images segments in one launch (in_scale / in_shift [nseg, C]; stats rows split by segment)."""
-    _chk(x, w, in_scale, in_shift, bias, residual, out)
+    _chk(x, w, in_scale, in_shift, bias, residual, out, out_scale)
     dt = _dt(x)
     N, H, W, C = x.shape
     K, R, S, C2 = w.shape
@@ -58,6 +59,7 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
                    N, H, W, C, K, R, S, stride, pad, PH, PW, OH, OW, osh, int(transposed), int(in_relu), int(relu),
                    int(accumulate), int(pix_mul), int(pix_off[0]), int(pix_off[1]), int(tap_mask))
     d.par4 = int(par4)
+    d.out_scale = L.ptr(out_scale)
     if seg_images:
         d.seg_images = int(seg_images)
         d.seg_stride = int(in_scale.stride(0)) if in_scale is not None and in_scale.dim() == 2 else 0
@@ -79,10 +81,10 @@ def conv2d(x, w, stride, pad, *, in_scale=None, in_shift=None, in_relu=False, bi
     return (y, stats) if want_stats else y
 
 
-def conv2d_s2_pair(x, w3, w1, *, bias3=None, bias1=None, relu3=False, want_stats=False):
+def conv2d_s2_pair(x, w3, w1, *, bias3=None, bias1=None, relu3=False, want_stats=False, scale3=None, scale1=None):
     """a downsampling BasicBlock's conv1 (3x3 / 2 / pad 1, w3 [K,3,3,C]) and projection (1x1 / 2, w1 [K,1,1,C]) of ONE input in one
     launch (sslcr_conv2d_s2_pair) -> (y3, yd) or (y3, yd, stats3, statsd)"""
-    _chk(x, w3, w1, bias3, bias1)
+    _chk(x, w3, w1, bias3, bias1, scale3, scale1)
     dt = _dt(x)
     N, H, W, C = x.shape
     K = w3.shape[0]
@@ -94,6 +96,7 @@ def conv2d_s2_pair(x, w3, w1, *, bias3=None, bias1=None, relu3=False, want_stats
                     N, H, W, C, K, 3, 3, 2, 1, PH, PW, PH, PW, 1, 0, 0, int(relu3), 0, 0, 0, 0, 0)
     d1 = L.ConvDesc(L.ptr(x), L.ptr(w1), L.ptr(yd), None, None, L.ptr(bias1), None, None,
                     N, H, W, C, K, 1, 1, 2, 0, PH, PW, PH, PW, 1, 0, 0, 0, 0, 0, 0, 0, 0)
+    d3.out_scale, d1.out_scale = L.ptr(scale3), L.ptr(scale1)
     s3 = sd = None
     if want_stats:
         rows = L.lib().sslcr_conv2d_partial_rows(d3)
@@ -156,9 +159,10 @@ def conv2d_wgrad(x, dy, dw, R, S, stride, pad, *, in_scale=None, in_shift=None, 
     L.check(L.lib().sslcr_conv2d_wgrad(_dt(x), d, L.stream_ptr()))
 
 
-def pack_conv(w_kcrs, dtype, *, fwd=True, dgrad=False, bn=None, eps=1e-5, dgrad_flip=False):
+def pack_conv(w_kcrs, dtype, *, fwd=True, dgrad=False, bn=None, eps=1e-5, dgrad_flip=False, unfold=False):
     """PyTorch [K,C,R,S] fp32 -> (w_fwd [K,R,S,C], w_dgrad [C,R,S,K], bias[K]|None) in engine dtype.
-    bn = (gamma, beta, running_mean, running_var) folds eval-mode BatchNorm into w_fwd/bias."""
+    bn = (gamma, beta, running_mean, running_var) folds eval-mode BatchNorm into w_fwd/bias; with unfold the filter stays plain and
+    the BatchNorm scale is returned as a fourth value (sslcr_pack_desc.scale_out -> sslcr_conv_desc.out_scale)."""
     _chk(w_kcrs)
     K, C, R, S = w_kcrs.shape
     dev = w_kcrs.device
@@ -166,24 +170,26 @@ def pack_conv(w_kcrs, dtype, *, fwd=True, dgrad=False, bn=None, eps=1e-5, dgrad_
     wd = torch.empty((C, R, S, K), dtype=tdtype(dtype), device=dev) if dgrad else None
     bias = torch.empty(K, dtype=torch.float32, device=dev) if bn is not None else None
     g, b, rm, rv = bn if bn is not None else (None, None, None, None)
+    scale = torch.empty(K, dtype=torch.float32, device=dev) if (unfold and bn is not None) else None
     d = L.PackDesc(L.ptr(w_kcrs), L.ptr(wf), L.ptr(wd), L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), eps, L.ptr(bias),
-                   K, C, R, S, int(dgrad_flip))
+                   K, C, R, S, int(dgrad_flip), L.ptr(scale))
     L.check(L.lib().sslcr_pack_conv(dtype, d, L.stream_ptr()))
-    return wf, wd, bias
+    return (wf, wd, bias, scale) if unfold else (wf, wd, bias)
 
 
-def pack_stem(w_kcrs, dtype, *, bn=None, eps=1e-5):
+def pack_stem(w_kcrs, dtype, *, bn=None, eps=1e-5, unfold=False):
     _chk(w_kcrs)
     dev = w_kcrs.device
     wf = torch.empty((64, 7, 8, 4), dtype=tdtype(dtype), device=dev)
     bias = torch.empty(64, dtype=torch.float32, device=dev) if bn is not None else None
     g, b, rm, rv = bn if bn is not None else (None, None, None, None)
-    d = L.PackDesc(L.ptr(w_kcrs), L.ptr(wf), None, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), eps, L.ptr(bias), 64, 3, 7, 7, 0)
+    scale = torch.empty(64, dtype=torch.float32, device=dev) if (unfold and bn is not None) else None
+    d = L.PackDesc(L.ptr(w_kcrs), L.ptr(wf), None, L.ptr(g), L.ptr(b), L.ptr(rm), L.ptr(rv), eps, L.ptr(bias), 64, 3, 7, 7, 0, L.ptr(scale))
     L.check(L.lib().sslcr_pack_stem(dtype, d, L.stream_ptr()))
-    return wf, bias
+    return (wf, bias, scale) if unfold else (wf, bias)
 
 
-def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False, x2=None):
+def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False, x2=None, out_scale=None):
     """x NCHW uint8|fp32 [N,3,H,W] (optionally followed by a second segment x2, read in place of a torch.cat)
     -> NHWC [N(+N2),OH,OW,64] in w_packed's dtype (+ partial stats)."""
     _chk(x_nchw, w_packed, bias, x2)
@@ -195,8 +201,9 @@ def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False, x2=N
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     assert x_nchw.dtype in (torch.uint8, torch.float32)
     y = torch.empty((N, OH, OW, 64), dtype=w_packed.dtype, device=x_nchw.device)
+    _chk(out_scale)
     d = L.StemDesc(L.ptr(x_nchw), L.ptr(w_packed), L.ptr(y), L.ptr(bias), None, N, H, W, OH, OW,
-                   int(x_nchw.dtype == torch.float32), int(relu), L.ptr(x2), int(n_split))
+                   int(x_nchw.dtype == torch.float32), int(relu), L.ptr(x2), int(n_split), L.ptr(out_scale))
     stats = None
     if want_stats:
         rows = L.lib().sslcr_stem_partial_rows(d)
@@ -206,7 +213,7 @@ def stem_conv(x_nchw, w_packed, *, bias=None, relu=False, want_stats=False, x2=N
     return (y, stats) if want_stats else y
 
 
-def stem_conv_pool(x_nchw, w_packed, bias, *, x2=None):
+def stem_conv_pool(x_nchw, w_packed, bias, *, x2=None, out_scale=None):
     """eval-mode stem in one launch: conv1 (folded BatchNorm: bias) -> ReLU -> maxpool 3x3/2 pad 1 -> NHWC [N, OH/2, OW/2, 64] (bf16)."""
     _chk(x_nchw, w_packed, bias, x2)
     N, _, H, W = x_nchw.shape
@@ -216,8 +223,9 @@ def stem_conv_pool(x_nchw, w_packed, bias, *, x2=None):
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     POH, POW = OH // 2, OW // 2
     y = torch.empty((N, POH, POW, 64), dtype=w_packed.dtype, device=x_nchw.device)
+    _chk(out_scale)
     d = L.StemDesc(L.ptr(x_nchw), L.ptr(w_packed), L.ptr(y), L.ptr(bias), None, N, H, W, OH, OW,
-                   int(x_nchw.dtype == torch.float32), 1, L.ptr(x2), int(n_split))
+                   int(x_nchw.dtype == torch.float32), 1, L.ptr(x2), int(n_split), L.ptr(out_scale))
     L.check(L.lib().sslcr_stem_conv_pool(_dt(w_packed), d, POH, POW, L.stream_ptr()))
     return y
 

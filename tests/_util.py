@@ -50,6 +50,22 @@ def held(key, err, ceiling, floor=0.0, what=""):
     return err
 
 
+_YARD_SMALL = None
+
+
+def yard_small(name, q, ceiling, scalar=True):
+    """independent bf16 ceiling of a SMALL-epoch quantity (round 6; until then these keys sat under flat 6e-2 / 1e-1 / 0.2 constants):
+    a multiple of what bf16 STORAGE alone does to that quantity in the CPU emulation of the same epoch (tests/golden/
+    make_bf16_yard_small.py -> bf16_yard_small.npz; oracle/bf16_emul.py:emulating).  Scalars (loss averages, validate()) are sums of
+    partly cancelling rounding errors over a handful of images -- 10 x the emulated figure, floored at 1e-2; element-wise feature
+    comparisons 3 x.  Never above the old constant."""
+    global _YARD_SMALL
+    if _YARD_SMALL is None:
+        _YARD_SMALL = np.load(os.path.join(GOLD, "bf16_yard_small.npz"))
+    e = float(_YARD_SMALL[f"{name}/{q}_err"][0])
+    return min(ceiling, max(10.0 * e, 1e-2) if scalar else 3.0 * e)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLD, f"{name}.npz"), allow_pickle=False)
 

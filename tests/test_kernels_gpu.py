@@ -181,6 +181,97 @@ def test_conv_fwd_fused_prologue_epilogue(shape, dtype):
     close(y, want, TOL[dtype], "fused conv")
 
 
+OSC_CASES = [
+    # N, H, W, C, K, R, stride, pad, residual, kernel the bf16 launch must land on (None: whatever serves it)
+    (2, 32, 32, 128, 128, 3, 1, 1, True, "conv3x3_h16_kernel"),       # 16x16 tiles, the teacher's conv2 form
+    (33, 32, 32, 64, 256, 3, 1, 1, False, "conv3x3_h16_kernel"),      # a workgroup walks into a second kout block
+    (4, 8, 8, 256, 512, 3, 1, 1, True, ", 8>"),                        # four-image tiles
+    (320, 8, 8, 64, 512, 3, 1, 1, False, ", 8>"),                      # ... head + 64-kout tail launches
+    (40, 32, 32, 64, 64, 3, 1, 1, True, "conv3x3_pp64_kernel"),        # layer1 ping-pong form, residual instance
+    (40, 32, 32, 64, 64, 3, 1, 1, False, "conv3x3_pp64_kernel"),
+    (6, 64, 64, 64, 128, 3, 2, 1, False, "conv_s2_kernel<false, true>"),
+    (6, 32, 64, 256, 384, 3, 2, 1, False, "conv_s2_kernel<false, true>"),   # kout-block-major walk: the block's bias / scale are reloaded
+    (10, 30, 34, 64, 128, 3, 2, 1, False, "conv_dma_kernel"),
+    (9, 32, 32, 64, 128, 1, 2, 0, False, "conv_dma_kernel"),
+    (3, 9, 11, 64, 128, 3, 2, 1, False, None),                         # ragged: generic gather kernel
+    (1, 24, 16, 64, 64, 3, 1, 1, True, None),                          # 128-pixel halo kernel
+    (2, 8, 8, 256, 64, 3, 1, 1, True, None),
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", OSC_CASES)
+def test_conv_out_scale(case, dtype):
+    """sslcr_conv_desc.out_scale (round 6): eval-mode BatchNorm with its scale kept OUT of the filters -- y = relu(acc * scale + bias
+    [+ residual]) -- in every kernel that serves a bias epilogue, against the plain conv times the scale; and the scale of ones gives the
+    bits of the launch without it"""
+    K = _k()
+    N, H, W, C, Ko, Rr, stride, pad, with_res, expect = case
+    x = q(rnd(81, (N, H, W, C)), dtype)
+    w = q(rnd(82, (Ko, Rr, Rr, C), 0.05), dtype)
+    bias, sc = rnd(83, (Ko,)), rnd(84, (Ko,)).abs() + 0.25
+    sc[::3] *= -1.0                                          # gamma may be negative
+    OH, OW = (H + 2 * pad - Rr) // stride + 1, (W + 2 * pad - Rr) // stride + 1
+    res = q(rnd(85, (N, OH, OW, Ko)), dtype) if with_res else None
+    kw = dict(bias=bias.to(DEV), residual=to_dev(res, dtype) if with_res else None, relu=True)
+    y = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), stride, pad, out_scale=sc.to(DEV), **kw)
+    if expect and dtype == 1:
+        assert expect in K.last_conv_kernel, K.last_conv_kernel
+    close(y, R.conv_fwd(x, w, stride, pad, bias=bias, residual=res, relu=True, out_scale=sc), TOL[dtype], "conv with output scale")
+    y1 = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), stride, pad, out_scale=torch.ones(Ko, device=DEV), **kw)
+    y0 = K.conv2d(to_dev(x, dtype), to_dev(w, dtype), stride, pad, **kw)
+    assert torch.equal(y1, y0)
+
+
+@pytest.mark.parametrize("shape", [(6, 64, 64, 64, 128), (9, 32, 32, 128, 256), (6, 32, 64, 256, 384)])
+def test_conv_s2_pair_out_scale(shape):
+    """the eval pair (conv1 3x3 / 2 + 1x1 / 2 projection in one launch) with both BatchNorm scales in the epilogue"""
+    K = _k()
+    N, H, W, C, Ko = shape
+    x = q(rnd(91, (N, H, W, C)), 1)
+    w3, w1 = q(rnd(92, (Ko, 3, 3, C), 0.05), 1), q(rnd(93, (Ko, 1, 1, C), 0.1), 1)
+    b3, b1, s3, s1 = rnd(94, (Ko,)), rnd(95, (Ko,)), rnd(96, (Ko,)).abs() + 0.25, -(rnd(97, (Ko,)).abs() + 0.25)
+    y3, yd = K.conv2d_s2_pair(to_dev(x, 1), to_dev(w3, 1), to_dev(w1, 1), bias3=b3.to(DEV), bias1=b1.to(DEV), relu3=True,
+                              scale3=s3.to(DEV), scale1=s1.to(DEV))
+    close(y3, R.conv_fwd(x, w3, 2, 1, bias=b3, relu=True, out_scale=s3), TOL[1], "eval 3x3 with scale")
+    close(yd, R.conv_fwd(x, w1, 2, 0, bias=b1, out_scale=s1), TOL[1], "eval 1x1 with scale")
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_pack_unfolded_and_stem_out_scale(dtype):
+    """sslcr_pack_desc.scale_out: the eval pack keeps the plain filter and hands out gamma / sqrt(var + eps); the stem kernels (conv, and
+    conv + max-pool in one launch) apply it in their epilogues.  Against torch's eval-mode conv1 -> bn1 -> relu (-> maxpool)."""
+    K = _k()
+    N, H = 3, 64
+    xu = torch.from_numpy(np.random.RandomState(71).randint(0, 256, (N, 3, H, H), dtype=np.uint8))
+    w = rnd(72, (64, 3, 7, 7), 0.03)
+    g, b, rm, rv = rnd(73, (64,)).abs() + 0.5, rnd(74, (64,)), rnd(75, (64,)), rnd(76, (64,)).abs() + 0.5
+    g[::4] *= -1.0
+    bn = tuple(t.to(DEV) for t in (g, b, rm, rv))
+    wp, bias, scale = K.pack_stem(w.to(DEV), dtype, bn=bn, unfold=True)
+    wp0, _ = K.pack_stem(w.to(DEV), dtype)
+    f = g / torch.sqrt(rv + 1e-5)
+    assert torch.equal(wp, wp0)                                  # the plain filter
+    close(scale, f, 1e-6, "scale_out")
+    close(bias, b - rm * f, 1e-5, "bias_out")
+    want = F.relu(R.nhwc(F.conv2d(xu.float(), q(w, dtype), None, 2, 3)) * f + (b - rm * f))
+    y = K.stem_conv(xu.to(DEV), wp, bias=bias, relu=True, out_scale=scale)
+    close(y, want, TOL[dtype], "stem with output scale")
+    if dtype == 1:
+        yp = K.stem_conv_pool(xu.to(DEV), wp, bias, out_scale=scale)
+        wantp = R.nhwc(F.max_pool2d(R.nchw(q(want, 1)), 3, 2, 1))
+        close(yp, wantp, TOL[1], "stem + pool with output scale")
+    # a 3x3 filter bank
+    w3 = rnd(77, (128, 64, 3, 3), 0.05)
+    g3, b3, rm3, rv3 = rnd(78, (128,)).abs() + 0.5, rnd(79, (128,)), rnd(80, (128,)), rnd(81, (128,)).abs() + 0.5
+    wf, _, bias3, scale3 = K.pack_conv(w3.to(DEV), dtype, bn=tuple(t.to(DEV) for t in (g3, b3, rm3, rv3)), unfold=True)
+    wf0, _, _ = K.pack_conv(w3.to(DEV), dtype)
+    f3 = g3 / torch.sqrt(rv3 + 1e-5)
+    assert torch.equal(wf, wf0)
+    close(scale3, f3, 1e-6, "scale_out 3x3")
+    close(bias3, b3 - rm3 * f3, 1e-5, "bias_out 3x3")
+
+
 @pytest.mark.parametrize("dtype", [0, 1])
 @pytest.mark.parametrize("shape", [(4, 8, 8, 512, 512), (320, 8, 8, 64, 512), (12, 8, 8, 128, 128), (2, 32, 32, 128, 128)])
 def test_conv_eval_fused_epilogue_four_image_tiles(shape, dtype):
