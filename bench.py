@@ -587,8 +587,10 @@ def parity_record(out):
     """What the headline mode is held to (tests/measured_errors.json: errors measured on the MI355X against the REFERENCE's own
     full-size iteration, tests/golden/bpq_cr_full.npz) next to the mode that holds north_star's 1e-3."""
     rec = {"mode": out["dtype"], "north_star_1e-3_mode": "fp32",
-           "note": "value is measured in `mode`; the 1e-3 bound on logits / losses against the reference holds in the fp32 engine mode "
-                   "(--dtype fp32), whose throughput is fp32_images_per_s"}
+           "note": "value is measured in `mode`.  Since round 6 (eval-mode BatchNorm scale kept out of the bf16 filters) the bf16 mode's LOSS "
+                   "of this workload's full-size iteration is within 1e-3 of the reference (loss_rel_err_vs_reference); element-wise "
+                   "logits / features are bf16 storage (1e-2) -- the 1e-3 bound on logits, features and trajectories holds in the fp32 "
+                   "engine mode (--dtype fp32), whose throughput is fp32_images_per_s"}
     try:
         m = json.load(open(os.path.join(ROOT, "tests", "measured_errors.json")))
         k = "bf16" if out["dtype"] in ("bf16", "fp8") else out["dtype"]
