@@ -205,6 +205,80 @@ def cpu_baseline(args):
             "timed_out": timed_out}
 
 
+# ------------------------------------------------------------------------------------------------ clock / power next to the roofline
+class PowerSampler:
+    """sclk and socket power of THIS process's GPU while a leg runs (a thread reading the amdgpu hwmon files every 20 ms; `rocm-smi
+    --json` where they are not readable): the power-cap argument of DESIGN.md as numbers in the bench line.  Best effort: any failure
+    leaves a note instead of numbers."""
+
+    def __init__(self, device_index=0, period=0.02):
+        import threading
+        self.period, self.rows, self.note, self.hw = period, [], None, None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            import glob
+            for card in glob.glob("/sys/class/drm/card*/device"):
+                if bdf in os.path.realpath(card):
+                    hm = glob.glob(os.path.join(card, "hwmon", "hwmon*"))
+                    if hm and os.path.exists(os.path.join(hm[0], "freq1_input")):
+                        self.hw = hm[0]
+            if self.hw is None:
+                self.note = f"no hwmon directory for PCI device {bdf}*; rocm-smi --json instead"
+        except Exception as e:                                  # noqa: BLE001
+            self.note = f"hwmon lookup failed ({type(e).__name__}: {e}); rocm-smi --json instead"
+
+    def _read(self):
+        if self.hw:
+            f = int(open(os.path.join(self.hw, "freq1_input")).read()) / 1e6
+            pw = None
+            for name in ("power1_input", "power1_average"):
+                q = os.path.join(self.hw, name)
+                if os.path.exists(q):
+                    pw = int(open(q).read()) / 1e6
+                    break
+            return f, pw
+        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=5)
+        d = next(iter(json.loads(r.stdout.strip().splitlines()[-1]).values()))
+        f = float(d["sclk clock speed:"].strip("()Mhz"))
+        pw = next((float(v) for k, v in d.items() if "Power (W)" in k), None)
+        return f, pw
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.rows.append(self._read())
+            except Exception as e:                              # noqa: BLE001
+                self.note = f"sampling failed ({type(e).__name__}: {e})"
+                return
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=10)
+        return False
+
+    def summary(self):
+        fs = [r[0] for r in self.rows if r[0] is not None]
+        ps = [r[1] for r in self.rows if r[1] is not None]
+        out = {"samples": len(self.rows), "source": "amdgpu hwmon (freq1_input = sclk, power1_input)" if self.hw else "rocm-smi --json"}
+        if fs:
+            out.update(sclk_mhz_mean=round(sum(fs) / len(fs), 1), sclk_mhz_min=round(min(fs), 1), sclk_mhz_max=round(max(fs), 1))
+        if ps:
+            out.update(socket_power_w_mean=round(sum(ps) / len(ps), 1), socket_power_w_max=round(max(ps), 1))
+        if self.hw and os.path.exists(os.path.join(self.hw, "power1_cap")):
+            out["socket_power_cap_w"] = round(int(open(os.path.join(self.hw, "power1_cap")).read()) / 1e6, 1)
+        if self.note:
+            out["note"] = self.note
+        return out
+
+
 # ------------------------------------------------------------------------------------------------ workloads
 def make_workload(name, eng, args, device, rank, world, modules_student=None):
     """-> (step(), distinct patches per step, algorithmic FLOPs per step, config dict)"""
@@ -614,7 +688,17 @@ def run_rank(args, rank, world, device, eng, ranks, want_transport):
 
     step, patches, flops_step, cfg, keep = make_workload(args.workload, eng, args, device, rank, world)
     per_step_ms = []
+    # sclk and socket power of this GPU over the warm-up and the timed steps themselves (rank 0; a thread reading two sysfs files every
+    # 20 ms): the clock the value was measured at.  (A separate one-second leg in front of the roofline leg was tried first: the part
+    # settles ~5 % lower after a second of sustained load, which moved the per-kernel numbers of that leg away from the timed region's.)
+    sampler = PowerSampler(device.index or 0) if rank == 0 else None
+    if sampler:
+        sampler.__enter__()
     dt = timed(step, args.warmup, args.steps, barrier, per_step_ms)
+    power = None
+    if sampler:
+        sampler.__exit__()
+        power = sampler.summary()
     dt = ranks.max_over_ranks(rank, dt)
     ms_per_step = dt / args.steps * 1e3
     value = patches * world * args.steps / dt
@@ -632,6 +716,8 @@ def run_rank(args, rank, world, device, eng, ranks, want_transport):
            "per_gpu_images_per_s": round(value / (1 if want_transport == "virtual" else world), 1),
            "achieved_tflops_per_gpu_algorithmic": round(flops_step * (world if want_transport == "virtual" else 1) / (ms_per_step * 1e-3) / 1e12, 2),
            "ranks_seen": cworld, "collective_transport": transport}
+    if power:
+        out["power_clock"] = power
     if want_transport == "virtual":
         out["virtual_ranks"] = world
         out["note"] = (f"{world} virtual ranks on ONE GPU (sslcr_vcomm): the sharded job's control flow, not a scaling number -- value is "
@@ -722,6 +808,13 @@ def rank0_only_legs(args, world, out, rows, nprof, ms_per_step, work):
             if args.dtype == "fp8":           # config 5: the roofline object is the fp8 kernel's (largest fp8 row), peak 5 PF
                 d = next((r for r in rows if "fp8" in r["name"]), d)
             out["roofline"] = roof(d)
+            pc = out.get("power_clock") or {}
+            if pc.get("sclk_mhz_mean"):
+                # the spec peak is quoted at the 2.4 GHz boost clock; under the socket power limit the step runs below it (power_clock):
+                # `frac` stays achieved / spec peak, this is the same achieved against the peak at the clock the part actually held
+                f = pc["sclk_mhz_mean"] / 2400.0
+                out["roofline"]["sclk_mhz_mean_of_step"] = pc["sclk_mhz_mean"]
+                out["roofline"]["frac_of_peak_at_measured_sclk"] = round(out["roofline"]["achieved"] / (out["roofline"]["peak"] * f), 4)
             if hbm_rows and hbm_rows[0]["ms"] > d["ms"]:
                 out["roofline_note"] = ("by total time the HBM-bound bn_bwd_apply kernel edges out the largest conv kernel; both "
                                         "roofs are reported (roofline = MFMA kernel, roofline_hbm = that kernel)")

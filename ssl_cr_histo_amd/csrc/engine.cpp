@@ -75,6 +75,8 @@ struct ConvL {
   // the loss error of the full-size iteration is 3.6 x smaller than with the scale folded in before the rounding; nullptr (fp32
   // mode): folded into w_fold
   float* s_fold = nullptr;
+  void* w_foldf = nullptr;        // stem only, with s_fold: the FOLDED eval pack for the shapes the fused conv + max-pool kernel does not take
+                                  // (stem_fwd_kernel has no output scale: its registers, see launch_stem)
   // fp8 engine mode (SSLCR_FP8): e4m3 shadow packs + per-kout dequant factors of the train / eval-folded filters, for the
   // convs the fp8 kernel serves (3x3 stride 1, cin and cout multiples of 128: layers 2-4)
   uint8_t *w8_fwd = nullptr, *w8_fold = nullptr;
@@ -472,6 +474,7 @@ int alloc_shadow(sslcr_net* n) {
     c.take(wbytes);                     // w_fold
     c.take(L.cout * sizeof(float));     // b_fold
     c.take(L.cout * sizeof(float));     // s_fold
+    if (L.pidx == 0) c.take(wbytes);    // w_foldf
     if (fp8_layer(n->ctx, L)) {         // w8_fwd, w8_fold, dq_fwd, dq_fold
       c.take((size_t)L.cout * 9 * L.cin); c.take((size_t)L.cout * 9 * L.cin);
       c.take(L.cout * sizeof(float)); c.take(L.cout * sizeof(float));
@@ -496,6 +499,7 @@ int alloc_shadow(sslcr_net* n) {
     {
       const size_t bb = (L.cout * sizeof(float) + 255) & ~(size_t)255;
       L.s_fold = unfold_eval(n->ctx) ? (float*)(base + 3 * wbytes + bb) : nullptr;
+      if (L.pidx == 0) L.w_foldf = base + 3 * wbytes + 2 * bb;
     }
     if (fp8_layer(n->ctx, L)) {
       const size_t bb = (L.cout * sizeof(float) + 255) & ~(size_t)255, w8 = ((size_t)L.cout * 9 * L.cin + 255) & ~(size_t)255;
@@ -540,6 +544,10 @@ int pack_conv_layer(sslcr_net* n, ConvL& L, const BnL& bn, int mode, hipStream_t
     a.bias_out = L.b_fold;
     a.scale_out = L.s_fold;                          // (non-null: w_fold is the plain filter, the scale goes to the epilogue)
     TRY(stem ? launch_pack_stem(dt, a, st) : launch_pack_conv(dt, a, st));
+    if (stem && L.s_fold && L.w_foldf) {             // ... and the folded form for the stem's two-kernel path
+      a.w_fwd = L.w_foldf; a.scale_out = nullptr;
+      TRY(launch_pack_stem(dt, a, st));
+    }
   }
   if (L.w8_fwd) {
     PackFp8Args f;
@@ -863,6 +871,7 @@ int backbone_forward_eval(sslcr_net* n, const void* const* xs, int npass, int in
       a.y = pooled;                                        // conv1 + folded BatchNorm + ReLU + max-pool in one launch: the conv output stays on the CU
       TRY(launch_stem_pool(dt, a, d.ph, d.pw, st));
     } else {
+      if (a.out_scale) { a.w = n->stem.w_foldf; a.out_scale = nullptr; }      // (the two-kernel path takes the folded pack)
       TRY(launch_stem(dt, a, st));
       PoolFwdArgs q;
       memset(&q, 0, sizeof(q));

@@ -247,17 +247,6 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const StemArgs a, int til
         }
       }
     }
-    // sslcr_stem_desc.out_scale (eval-mode BatchNorm scale kept out of the filters; bias forms only): acc * scale in place (uniform)
-    if (a.out_scale) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float sj = a.out_scale[STEM_CH(t, g, j)];
-          acc[t][0][j] *= sj;
-          acc[t][1][j] *= sj;
-        }
-    }
     // epilogue: lane holds kouts g*16 .. g*16+15 of pixel (ho0+2*wave+p, wo0+li)
     // (the kernel is VALU-bound -- 56 MFMAs against ~650 VALU per tile and wave -- so the common training case, a full tile
     // with no bias/ReLU, takes a path without the per-element selects, adds and the integer bf16 rounding)
@@ -355,6 +344,9 @@ static hipError_t launch_stem_t(const StemArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_stem(int dtype, const StemArgs& a, hipStream_t st) {
+  // sslcr_stem_desc.out_scale exists in the fused conv + max-pool kernel only (stem_pool.hip): here 16 more live values in the
+  // output stage took stem_fwd_kernel from 232 to 272 registers -- one wave per SIMD instead of two for the TRAIN forward too
+  if (a.out_scale) return hipErrorInvalidValue;
   if (dtype == DT_BF16) return a.in_f32 ? launch_stem_t<bf16_t, true>(a, st) : launch_stem_t<bf16_t, false>(a, st);
   return a.in_f32 ? launch_stem_t<float, true>(a, st) : launch_stem_t<float, false>(a, st);
 }

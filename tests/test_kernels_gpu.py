@@ -183,8 +183,8 @@ def test_conv_fwd_fused_prologue_epilogue(shape, dtype):
 
 OSC_CASES = [
     # N, H, W, C, K, R, stride, pad, residual, kernel the bf16 launch must land on (None: whatever serves it)
-    (2, 32, 32, 128, 128, 3, 1, 1, True, "conv3x3_h16_kernel"),       # 16x16 tiles, the teacher's conv2 form
-    (33, 32, 32, 64, 256, 3, 1, 1, False, "conv3x3_h16_kernel"),      # a workgroup walks into a second kout block
+    (2, 32, 32, 128, 128, 3, 1, 1, True, "conv3x3_h16s_kernel"),      # 16x16 tiles, the teacher's conv2 form (the output-scale instance)
+    (33, 32, 32, 64, 256, 3, 1, 1, False, "conv3x3_h16s_kernel"),     # a workgroup walks into a second kout block
     (4, 8, 8, 256, 512, 3, 1, 1, True, ", 8>"),                        # four-image tiles
     (320, 8, 8, 64, 512, 3, 1, 1, False, ", 8>"),                      # ... head + 64-kout tail launches
     (40, 32, 32, 64, 64, 3, 1, 1, True, "conv3x3_pp64_kernel"),        # layer1 ping-pong form, residual instance
@@ -255,8 +255,10 @@ def test_pack_unfolded_and_stem_out_scale(dtype):
     close(scale, f, 1e-6, "scale_out")
     close(bias, b - rm * f, 1e-5, "bias_out")
     want = F.relu(R.nhwc(F.conv2d(xu.float(), q(w, dtype), None, 2, 3)) * f + (b - rm * f))
-    y = K.stem_conv(xu.to(DEV), wp, bias=bias, relu=True, out_scale=scale)
-    close(y, want, TOL[dtype], "stem with output scale")
+    # the two-kernel stem has no output scale (its registers: launch_stem) -- it fails loudly, the engine gives it the folded pack
+    from ssl_cr_histo_amd import _lib as L
+    with pytest.raises(L.SslcrError):
+        K.stem_conv(xu.to(DEV), wp, bias=bias, relu=True, out_scale=scale)
     if dtype == 1:
         yp = K.stem_conv_pool(xu.to(DEV), wp, bias, out_scale=scale)
         wantp = R.nhwc(F.max_pool2d(R.nchw(q(want, 1)), 3, 2, 1))
