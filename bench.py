@@ -57,13 +57,13 @@ def parse():
     ap.add_argument("--bn-sync", type=int, default=1, choices=[0, 1],
                     help="N>1: 1 = train-mode BatchNorm on global-batch statistics (RCCL all-reduce of per-channel sums, the "
                          "north-star form); 0 = per-replica statistics like the reference's nn.DataParallel (gradient buckets only)")
-    ap.add_argument("--aux-stream", type=int, default=1, choices=[0, 1],
-                    help="1 (default since round 6) = teacher forward on a second HIP stream next to the student forward.  The roofline "
-                         "leg runs the same steps SERIALISED (sslcr_profile forces both side streams off: a per-kernel duration "
-                         "measured under a concurrent launch says nothing about the kernel)")
-    ap.add_argument("--wgrad-stream", type=int, default=1, choices=[0, 1],
-                    help="1 (default since round 6) = backward's weight-gradient launches on a second HIP stream; bit-identical.  "
-                         "Same-box, round 6 (profiles/r06_streams_ab.txt): neither stream alone moves the step, both together -0.2 ms")
+    ap.add_argument("--aux-stream", type=int, default=0, choices=[0, 1],
+                    help="1 = teacher forward on a second HIP stream next to the student forward.  Off by default: round 6 measured both "
+                         "side streams on five boxes (profiles/r06_streams_ab.txt) -- with them every box lands at 15.5-15.6 ms, without "
+                         "them the same boxes run 15.2-15.75 ms: a gain on the slow boxes, a loss on the fast ones, zero on average.  The "
+                         "roofline leg is always serialised (sslcr_profile forces both off)")
+    ap.add_argument("--wgrad-stream", type=int, default=0, choices=[0, 1],
+                    help="1 = backward's weight-gradient launches on a second HIP stream; bit-identical.  See --aux-stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the other configurations (forward-only, RSP, frozen, fp32 parity, config 5)")

@@ -393,7 +393,8 @@ int sslcr_comm_init_virtual(sslcr_ctx* ctx, sslcr_vcomm* v, int rank);
 int sslcr_set_bn_sync(sslcr_ctx* ctx, int on);
 /* on: sslcr_step_ssl_cr runs the (frozen, eval-mode) teacher forward on a second HIP stream next to the student forward --
  * the workgroups of one fill the tail rounds of the other's kernels (measured -0.4 ms of a 20.4 ms step in round 1; in round 6,
- * 15.4 ms step: +-0 alone, -0.2 ms together with sslcr_set_wgrad_stream).  Off by default in the library; bench.py turns it on.
+ * five boxes: together with sslcr_set_wgrad_stream every box runs the step in 15.5-15.6 ms where the serial step takes 15.2-15.75 ms
+ * by box -- a gain on slow boxes, a loss on fast ones).  Off by default.
  * Forced off while sslcr_profile() is on: concurrent launches share the CUs, which makes per-kernel durations meaningless as a
  * statement about the kernel, and bench.py's roofline is built from those. */
 int sslcr_set_aux_stream(sslcr_ctx* ctx, int on);
