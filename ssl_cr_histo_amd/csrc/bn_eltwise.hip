@@ -347,8 +347,22 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const PoolFwdArgs 
 // PLAIN (scale == nullptr): x is pooled as it is -- the eval path, where conv1's epilogue already applied the folded BatchNorm and
 // the ReLU.  No affine, no ReLU, no argmax, and no validity selects either: a clamped address re-reads a pixel of the same window,
 // and a duplicate does not change a maximum.  9 x (unpack + max) instead of 9 x (unpack + fma + max + compare + 2 selects).
+// Which output rows a workgroup of the row-form pooling kernels walks.  bands (round 6, SSLCR_POOL_BANDS=1; measured slower, off): workgroup b runs on XCD b % 8; XCD x owns the
+// x-th eighth of the rows and each of its workgroups a contiguous run of that eighth, so the input row that two consecutive output rows
+// share (2 oh + 1 = 2 (oh + 1) - 1) is read once -- by the same workgroup -- instead of by two workgroups on two XCDs (rows b, b + G, ...:
+// the input crossed the fabric 1.5 x).  Same arithmetic per row, same bits.
+__device__ __forceinline__ void pool_row_range(int rows, int bands, int& r_begin, int& r_end, int& r_step) {
+  const int G = (int)gridDim.x, b = (int)blockIdx.x;
+  if (!bands || (G & 7)) { r_begin = b; r_end = rows; r_step = G; return; }
+  const int x = b & 7, j = b >> 3, gpx = G >> 3;
+  const int x0 = (int)((long)rows * x / 8), x1 = (int)((long)rows * (x + 1) / 8);
+  r_begin = x0 + (int)((long)(x1 - x0) * j / gpx);
+  r_end = x0 + (int)((long)(x1 - x0) * (j + 1) / gpx);
+  r_step = 1;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_rows_kernel(const PoolFwdArgs a) {
+__global__ __launch_bounds__(256) void maxpool_rows_kernel(const PoolFwdArgs a, const int bands) {
   constexpr int EPC = Elem<T>::EPC;
   const int cols = a.C / EPC;
   const int ppp = 256 / cols;
@@ -356,7 +370,9 @@ __global__ __launch_bounds__(256) void maxpool_rows_kernel(const PoolFwdArgs a) 
   const char* x = reinterpret_cast<const char*>(a.x) + (size_t)col * 16;
   const int rows = a.N * a.OH;
   const size_t rowb = (size_t)a.W * a.C * sizeof(T);
-  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+  int r_begin, r_end, r_step;
+  pool_row_range(rows, bands, r_begin, r_end, r_step);
+  for (int r = r_begin; r < r_end; r += r_step) {
     const int n = r / a.OH, oh = r - n * a.OH;
     const int h0 = 2 * oh - 1;
     const char* xn = x + (size_t)n * a.H * rowb;
@@ -386,7 +402,7 @@ __global__ __launch_bounds__(256) void maxpool_rows_kernel(const PoolFwdArgs a) 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(const PoolFwdArgs a) {
+__global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(const PoolFwdArgs a, const int bands) {
   constexpr int EPC = Elem<T>::EPC;
   const int cols = a.C / EPC;
   const int ppp = 256 / cols;                 // output pixels per pass
@@ -397,7 +413,9 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(const PoolFwd
   for (int e = 0; e < EPC; ++e) { psc[e] = a.scale[col * EPC + e]; psh[e] = a.shift[col * EPC + e]; }
   const int rows = a.N * a.OH;
   const size_t rowb = (size_t)a.W * a.C * sizeof(T);
-  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+  int r_begin, r_end, r_step;
+  pool_row_range(rows, bands, r_begin, r_end, r_step);
+  for (int r = r_begin; r < r_end; r += r_step) {
     const int n = r / a.OH, oh = r - n * a.OH;
     const int h0 = 2 * oh - 1;
     const char* xn = x + (size_t)n * a.H * rowb;
@@ -446,20 +464,23 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_rows_kernel(const PoolFwd
 }
 
 hipError_t launch_bn_relu_maxpool(int dtype, const PoolFwdArgs& a, hipStream_t st) {
+  // OFF: measured +0.07 ms per step on one box (15.39 -> 15.46 ms, three alternations) -- the input row two output rows share comes from
+  // L2 / the Infinity Cache either way, and interleaved rows keep more channels busy
+  static const int bands = [] { const char* e = getenv("SSLCR_POOL_BANDS"); return (e && atoi(e) != 0) ? 1 : 0; }();
   size_t px = (size_t)a.N * a.OH * a.OW;
   const int cols = a.C / (dtype == DT_BF16 ? 8 : 4);
   if (!a.scale || !a.shift) {          // plain max-pool (capi.cpp admits it only without argmax and for the row form's widths)
     const int rows = a.N * a.OH;
     const int grid = rows < 256 * 16 ? rows : 256 * 16;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(maxpool_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(maxpool_rows_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(maxpool_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, bands);
+    else hipLaunchKernelGGL(maxpool_rows_kernel<float>, dim3(grid), dim3(256), 0, st, a, bands);
     return hipGetLastError();
   }
   if (cols >= 1 && cols <= 256 && 256 % cols == 0) {
     const int rows = a.N * a.OH;
     const int grid = rows < 256 * 16 ? rows : 256 * 16;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(bn_relu_maxpool_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(bn_relu_maxpool_rows_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+    if (dtype == DT_BF16) hipLaunchKernelGGL(bn_relu_maxpool_rows_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a, bands);
+    else hipLaunchKernelGGL(bn_relu_maxpool_rows_kernel<float>, dim3(grid), dim3(256), 0, st, a, bands);
     return hipGetLastError();
   }
   if (dtype == DT_BF16) {
