@@ -4,7 +4,12 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+// the product kernel (its SSLCR_S2_PROF phase counters); -DS2_ABL_COPY: the round-5 measurement copy that carries the timing-only S2_ABL_* switches
+#ifdef S2_ABL_COPY
 #include "conv_s2_abl.hip"
+#else
+#include "../../ssl_cr_histo_amd/csrc/conv_s2.hip"
+#endif
 namespace sslcr {
 int device_cus() { return 256; }
 }

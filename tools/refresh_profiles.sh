@@ -13,7 +13,7 @@ mkdir -p $O
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py > $O/bench_under_rocprofv3.json 2> $O/bench_under_rocprofv3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python $R/bench.py --aux-stream 0 --wgrad-stream 0 > $O/bench_under_rocprofv3.json 2> $O/bench_under_rocprofv3.err
 cp $O/prof/p_kernel_stats.csv $O/kernel_stats.csv 2>/dev/null || cp $(find $O/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 rm -rf $O/prof
 cd $R
