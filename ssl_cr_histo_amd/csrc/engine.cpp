@@ -598,6 +598,42 @@ int finalize_bn(sslcr_net* n, const BnL& bn, const float* partials, int rows, do
   return 0;
 }
 
+// a downsampling block's bn1 and projection BatchNorm, whose statistics rows come out of ONE launch (the stride-2 pair): with synced
+// BatchNorm their sums share one all-reduce ([2][C] each, adjacent in bn_sums) -- 3 of the step's 37 latency-bound collectives less
+int finalize_bn_pair(sslcr_net* n, const BnL& b1, const float* part1, int rows1, const BnL& bd, const float* partd, int rowsd, double local_count,
+                     BnSaved& sv1, BnSaved& svd, int replay, hipStream_t st, int nseg, int seg_stride) {
+  sslcr_ctx* c = n->ctx;
+  if (!(sharded(c) && c->bn_sync) || b1.C != bd.C || nseg > 1) {
+    TRYI(finalize_bn(n, b1, part1, rows1, local_count, sv1, replay, st, nseg, seg_stride));
+    return finalize_bn(n, bd, partd, rowsd, local_count, svd, replay, st, nseg, seg_stride);
+  }
+  const BnL* bns[2] = {&b1, &bd};
+  const float* parts[2] = {part1, partd};
+  const int rowsv[2] = {rows1, rowsd};
+  BnSaved* svs[2] = {&sv1, &svd};
+  BnFinalizeArgs a[2];
+  for (int i = 0; i < 2; ++i) {
+    memset(&a[i], 0, sizeof(a[i]));
+    a[i].partials = parts[i]; a[i].rows = rowsv[i]; a[i].C = bns[i]->C;
+    a[i].gamma = n->params[bns[i]->pg]; a[i].beta = n->params[bns[i]->pb];
+    a[i].scale = svs[i]->scale; a[i].shift = svs[i]->shift; a[i].mean = svs[i]->mean; a[i].invstd = svs[i]->invstd;
+    a[i].running_mean = n->bn_rm[bns[i]->bidx]; a[i].running_var = n->bn_rv[bns[i]->bidx]; a[i].num_batches_tracked = n->bn_nbt[bns[i]->bidx];
+    if (n->f8_calib_pass) { a[i].running_mean = nullptr; a[i].running_var = nullptr; a[i].num_batches_tracked = nullptr; }
+    a[i].momentum = 0.1f; a[i].eps = 1e-5f; a[i].replay = replay;
+    a[i].stage = c->bn_stage; a[i].tickets = c->bn_tickets;
+    BnFinalizeArgs r = a[i];
+    r.sums_out = c->bn_sums + (size_t)i * 2 * b1.C;
+    TRY(launch_bn_finalize(r, st));                  // rows -> this rank's sums (the stage is consumed before the next launch reuses it)
+  }
+  TRYI(all_reduce(c, 0, c->bn_sums, 4 * (size_t)b1.C, true, st));
+  for (int i = 0; i < 2; ++i) {
+    a[i].sums_in = c->bn_sums + (size_t)i * 2 * b1.C;
+    a[i].count = local_count * c->world;
+    TRY(launch_bn_finalize(a[i], st));
+  }
+  return 0;
+}
+
 ConvArgs conv_args(const ConvL& L, const void* x, const void* w, void* y, int N, int H, int W) {
   ConvArgs a;
   memset(&a, 0, sizeof(a));
@@ -754,8 +790,19 @@ int forward_blocks(sslcr_net* n, PassState& ps, int N, int H, int W, int replay,
       a1.stats = part;
       ad.stats = (float*)((char*)c->partials.p + rb);
       TRY(prof_conv_pair(c, a1, ad, st));
-      TRYI(finalize_bn(n, B.b1, a1.stats, rows, cnt, ps.bn[B.b1.bidx], replay, st, nseg, seg_stride));
-      TRYI(finalize_bn(n, B.bd, ad.stats, rows, cnt, ps.bn[B.bd.bidx], replay, st, nseg, seg_stride));
+      TRYI(finalize_bn_pair(n, B.b1, a1.stats, rows, B.bd, ad.stats, rows, cnt, ps.bn[B.b1.bidx], ps.bn[B.bd.bidx], replay, st, nseg, seg_stride));
+    } else if (B.has_ds) {
+      // two launches (fp32, layer4.0's 8x8 maps, ragged shapes), the projection right behind conv1 so that the two BatchNorms still
+      // share one all-reduce of their sums when BatchNorm is synced across ranks
+      const int rows1 = conv_partials_rows(a1), rowsd = conv_partials_rows(ad);
+      const size_t rb1 = (((size_t)rows1 * 2 * a1.K * sizeof(float)) + 255) & ~(size_t)255;
+      TRYI(c->partials.ensure(rb1 + (size_t)rowsd * 2 * ad.K * sizeof(float)));
+      a1.stats = (float*)c->partials.p;
+      ad.stats = (float*)((char*)c->partials.p + rb1);
+      TRY(prof_conv(c, dt, a1, st));
+      TRY(prof_conv(c, dt, ad, st));
+      TRYI(finalize_bn_pair(n, B.b1, a1.stats, rows1, B.bd, ad.stats, rowsd, cnt, ps.bn[B.b1.bidx], ps.bn[B.bd.bidx], replay, st, nseg, seg_stride));
+      paired = true;                                   // (the projection has run: the block's tail below must not launch it again)
     } else {
       TRYI(ensure_partials(c, a1, &part, &rows, !segs && use_fp8(c, B.c1, a1)));
       a1.stats = part;
