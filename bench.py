@@ -57,8 +57,10 @@ def parse():
     ap.add_argument("--bn-sync", type=int, default=1, choices=[0, 1],
                     help="N>1: 1 = train-mode BatchNorm on global-batch statistics (RCCL all-reduce of per-channel sums, the "
                          "north-star form); 0 = per-replica statistics like the reference's nn.DataParallel (gradient buckets only)")
-    ap.add_argument("--aux-stream", type=int, default=0, choices=[0, 1],
-                    help="1 = teacher forward on a second HIP stream next to the student forward.  Off by default: round 6 measured both "
+    ap.add_argument("--aux-stream", type=int, default=-1, choices=[-1, 0, 1],
+                    help="1 = teacher forward on a second HIP stream next to the student forward; -1 (default) = on when the job is "
+                         "sharded (N > 1: the student's 34 BatchNorm all-reduces per step are latency-bound waits on its stream, which the "
+                         "teacher's eval forward -- no collectives -- can fill), off at N = 1: round 6 measured both "
                          "side streams on five boxes (profiles/r06_streams_ab.txt) -- with them every box lands at 15.5-15.6 ms, without "
                          "them the same boxes run 15.2-15.75 ms: a gain on the slow boxes, a loss on the fast ones, zero on average.  The "
                          "roofline leg is always serialised (sslcr_profile forces both off)")
@@ -401,6 +403,8 @@ def also_child(args):
     torch.cuda.set_device(device)
     from ssl_cr_histo_amd import engine as E
     eng = E.set_engine(E.Engine(device, "bf16"))
+    if args.aux_stream < 0:
+        args.aux_stream = 0
     eng.set_aux_stream(bool(args.aux_stream))          # the side streams as in the headline run
     eng.set_wgrad_stream(bool(args.wgrad_stream))
     also = {"side_streams": {"aux_stream": bool(args.aux_stream), "wgrad_stream": bool(args.wgrad_stream)}}
@@ -682,6 +686,8 @@ def run_rank(args, rank, world, device, eng, ranks, want_transport):
     """one rank of the job, from the workload to the final barrier.  `world` > 1: every step is full of collectives (BatchNorm sums,
     gradient buckets), so EVERY rank runs every step of every leg; what only rank 0 does (rank0_only_legs) calls nothing collective."""
     eng.set_bn_sync(bool(args.bn_sync))
+    if args.aux_stream < 0:
+        args.aux_stream = 1 if (world > 1 and args.bn_sync) else 0
     eng.set_aux_stream(bool(args.aux_stream))
     eng.set_wgrad_stream(bool(args.wgrad_stream))
     barrier = ranks.barrier
