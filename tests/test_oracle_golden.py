@@ -367,3 +367,28 @@ def test_bf16_yardstick_rsp_and_forward_only_are_pinned_to_the_reference():
     for mode in ("eval", "train"):
         assert rel_err(torch.from_numpy(y[f"fwd_full/{mode}/feats_rowl2_f64"]), g[f"fwd_full/{mode}/feats_rowl2"]) < 2e-6
         assert 1e-3 < float(y[f"fwd_full/{mode}/feats_err"][0]) < 2e-2
+
+
+def test_small_epoch_bf16_yardstick_is_pinned_to_the_reference():
+    """tests/golden/bf16_yard_small.npz (make_bf16_yard_small.py, oracle only): the fp32 leg of every small-epoch case returns the
+    losses / validate() values the REFERENCE's own epoch returned (the goldens; 2e-3: the de-triplicated oracle form), so the distance
+    of its bf16-storage leg from it is a distance from the reference's numbers; and the emulating() context leaves the oracle as it was."""
+    from oracle import bf16_emul as B
+    y = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bf16_yard_small.npz"))
+    idx = {"ret0": ("ret", 0), "ret1": ("ret", 1), "ret2": ("ret", 2), "val": ("val", 0)}
+    n = 0
+    for k in y.files:
+        if not k.endswith("_fp32"):
+            continue
+        name, q = k[:-5].split("/")
+        g = load_golden(name)
+        key, i = idx[q]
+        want = float(g[f"{name}/{key}"][i])
+        assert abs(float(y[k][0]) - want) <= 2e-3 * abs(want) + 1e-9, (k, float(y[k][0]), want)
+        assert 0.0 < float(y[f"{name}/{q}_err"][0]) < 0.2
+        n += 1
+    assert n >= 25
+    f = OM.backbone_forward
+    with B.emulating():
+        assert OM.backbone_forward is B.backbone_forward_emulated
+    assert OM.backbone_forward is f
